@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Benchmark of the attention-forward / row-softmax hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|config3|config5]
+
+N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL); every rank runs
+the same per-GPU workload on its own (batch x head) shard -- weak scaling, no
+collective on the timed path.  Rank 0 prints ONE JSON line:
+
+  metric / value   whole-job attention-forward TFLOP/s (4*B*H*N^2*d flops per pass per GPU),
+                   inputs resident in HBM, max-over-ranks wall time between barriers
+  roofline         the attention kernel against the dense bf16 MFMA peak (2.5 PFLOP/s):
+                   algorithmic flops per launch / mean launch duration from HIP events
+                   recorded around every timed launch on the launch stream
+  cpu_baseline     the C oracle (float32 arithmetic, OpenMP) timed on this host's cores on
+                   a bounded sample of the same workload (rank 0, N=1 only)
+  softmax_sweep    row-softmax GB/s (algorithmic 8 B/element) at n x n, n = 4096..32768,
+                   against 8 TB/s HBM peak (rank 0, N=1 only)
+  cpu_config1      torch CPU timings of BASELINE config 1 (softmax 1024^2, naive attention
+                   N=128 d=64), for reference beside the GPU numbers
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "flash-attention_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/f16 MFMA peak, MI355X
+HBM_PEAK_GBS = 8000.0       # HBM3E peak
+
+WORKLOADS = {
+    # name: (B, H, N, d, dtype) -- per GPU
+    "headline": (4, 32, 4096, 128, torch.bfloat16),    # BASELINE.json configs[3], the metric's config
+    "config3": (8, 16, 1024, 64, torch.float16),       # configs[2]
+    "config5": (1, 32, 16384, 128, torch.bfloat16),    # configs[4]: the shard one of 8 GPUs gets
+}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def attn_flops(B, H, N, d):
+    return 4.0 * B * H * N * N * d
+
+
+def bench_attention(mfa, B, H, N, d, dtype, steps, warmup, world, scale):
+    torch.manual_seed(1 + int(os.environ.get("RANK", "0")))
+    q, k, v = (torch.randn(B, H, N, d, dtype=dtype, device="cuda") for _ in range(3))
+    for _ in range(warmup):
+        out = mfa.flash_attn_fwd(q, k, v, scale=scale)
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        starts[i].record()
+        out = mfa.flash_attn_fwd(q, k, v, scale=scale)
+        stops[i].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    kern_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, stops))
+    mean_ms = sum(kern_ms) / len(kern_ms)
+    assert bool(torch.isfinite(out.float()).all())
+    return wall, mean_ms, kern_ms[len(kern_ms) // 2], (q, k, v, out)
+
+
+def bench_softmax_sweep(mfa, iters=20):
+    res = []
+    for n in (4096, 8192, 16384, 32768):
+        nbuf = 3 if n <= 8192 else 1      # rotate inputs larger than the 256 MiB Infinity Cache
+        xs = [torch.randn(n, n, dtype=torch.float32, device="cuda") for _ in range(nbuf)]
+        for i in range(3):
+            out = mfa.my_softmax(xs[i % nbuf], 1)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(ev):
+            a.record()
+            out = mfa.my_softmax(xs[i % nbuf], 1)
+            b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in ev)
+        med = ms[len(ms) // 2]
+        gbs = 2.0 * n * n * 4 / (med * 1e-3) / 1e9
+        res.append({"n": n, "us": round(med * 1e3, 2), "GB/s": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
+        del xs, out
+        torch.cuda.empty_cache()
+    return res
+
+
+def cpu_baseline(B, H, N, d, scale, budget_s=12.0):
+    """C oracle, float32 arithmetic, OpenMP: heads of the same workload until ~budget_s."""
+    import numpy as np
+    from oracle import c_oracle
+    c_oracle.build()
+    cores = min(16, os.cpu_count() or 1, c_oracle.max_threads())
+    c_oracle.set_threads(cores)
+    rng = np.random.default_rng(1)
+    q, k, v = (rng.standard_normal((1, N, d), dtype=np.float32) for _ in range(3))
+    t0 = time.perf_counter()
+    c_oracle.attention(q, k, v, scale=scale, f32_arith=True)
+    one = time.perf_counter() - t0
+    heads = int(max(1, min(B * H, budget_s / max(one, 1e-3))))
+    q, k, v = (rng.standard_normal((heads, N, d), dtype=np.float32) for _ in range(3))
+    t0 = time.perf_counter()
+    c_oracle.attention(q, k, v, scale=scale, f32_arith=True)
+    dt = time.perf_counter() - t0
+    return {"value": round(heads * attn_flops(1, 1, N, d) / dt / 1e12, 5), "unit": "TFLOP/s", "cores": cores,
+            "kind": "port", "seconds": round(dt, 2),
+            "sample": f"{heads} of the {B * H} (batch, head) problems of the workload, float32, N={N} d={d}"}
+
+
+def cpu_config1():
+    """BASELINE config 1 on the host with torch CPU ops (not part of any GPU number)."""
+    torch.manual_seed(1)
+    x = torch.randn(1024, 1024)
+    q, k, v = (torch.randn(128, 64) for _ in range(3))
+
+    def med(f, n):
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            f()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[n // 2]
+    t_s = med(lambda: torch.softmax(x, 1), 50)
+    t_a = med(lambda: torch.softmax(q @ k.t(), 1) @ v, 200)
+    return {"threads": torch.get_num_threads(), "cpu_count": os.cpu_count(),
+            "softmax_1024x1024_us": round(t_s * 1e6, 1), "softmax_GB/s": round(8 * 1024 * 1024 / t_s / 1e9, 2),
+            "naive_attention_N128_d64_us": round(t_a * 1e6, 1),
+            "naive_attention_GFLOP/s": round(4 * 128 * 128 * 64 / t_a / 1e9, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
+    ap.add_argument("--scale", default="rsqrt_d", choices=["rsqrt_d", "one"],
+                    help="logit scale: d^-0.5 (usual) or 1.0 (the reference's unscaled semantics)")
+    ap.add_argument("--no-extras", action="store_true", help="skip softmax sweep and CPU baselines")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import my_flash_attn_cuda as mfa   # raises if the HIP library is not built
+
+    B, H, N, d, dtype = WORKLOADS[args.workload]
+    scale = d ** -0.5 if args.scale == "rsqrt_d" else 1.0
+    wall, mean_ms, med_ms, _ = bench_attention(mfa, B, H, N, d, dtype, args.steps, args.warmup, world, scale)
+    flops = attn_flops(B, H, N, d)
+    value = world * args.steps * flops / wall / 1e12
+    achieved = flops / (mean_ms * 1e-3) / 1e12
+
+    result = {
+        "metric": "attn fwd TFLOP/s & %MFMA peak, B4 H32 N4096 d128 bf16; softmax GB/s",
+        "value": round(value, 2),
+        "unit": "TFLOP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": {torch.bfloat16: "bf16", torch.float16: "f16"}[dtype],
+        "data": "synthetic (torch.randn, seed 1 + rank), resident in HBM before timing",
+        "config": {"workload": f"attention forward {args.workload}: B={B} H={H} N={N} d={d} per GPU, "
+                               f"non-causal, scale={'d^-0.5' if args.scale == 'rsqrt_d' else '1.0'}",
+                   "B": B, "H": H, "N": N, "d": d, "sharding": f"batch x heads, {world} rank(s), no collective"},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "kernel": "attn_fwd_mfma_kernel", "launch_ms_mean": round(mean_ms, 4),
+                     "launch_ms_median": round(med_ms, 4), "flops_per_launch": flops},
+    }
+    if rank == 0 and world == 1 and not args.no_extras:
+        result["softmax_sweep"] = bench_softmax_sweep(mfa)
+        result["cpu_baseline"] = cpu_baseline(B, H, N, d, scale)
+        result["cpu_config1"] = cpu_config1()
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,309 @@
+// Fused attention forward for f16 / bf16 on gfx950 matrix cores.
+//
+//     O[b,h] = softmax(scale * Q[b,h] K[b,h]^T) V[b,h]      Q,K,V,O: [B,H,N,D], D in {64,128}
+//
+// This is the kernel the reference sketches and leaves as a TODO
+// (csrc/my_flash_attn/flash_attention.cu:23-69).  The math is the online-softmax
+// recurrence of its Python restatement (tests/test_flash_attn.py:82-93: running
+// rowmax m, rowsum l, rescale by exp(m_old - m_new)), in the loop order that keeps
+// a Q tile resident and streams K/V tiles past it, with O left un-normalised in
+// registers until one final division by l.
+//
+// Work decomposition
+//   workgroup = 8 waves = 256 query rows of one (batch, head); wave w owns rows
+//   32w..32w+31.  K/V are streamed in tiles of 64 keys, register-staged
+//   (global_load_dwordx4 issued one tile ahead, ds_write_b128 after the MFMAs)
+//   into a double-buffered LDS image; one barrier per tile.
+//
+// Register choreography (v_mfma_f32_32x32x16: D[32x32] += A[32x16] B[16x32])
+//   S^T = K Q^T : A = K rows (keys), B = Q^T, so the accumulator has the QUERY on
+//   the lane (col = lane & 31) and 16 keys in its registers; the two lane halves
+//   hold different keys of the same query.  Row max / row sum are therefore
+//   in-lane loops plus one half<->half exchange (v_permlane32_swap).
+//   O^T = V^T P^T : the S^T accumulator, converted to 16-bit in place, is already
+//   the B operand of this product (it sums over the accumulator's ROW index, the
+//   key), with the k order inside a 16-key step permuted to
+//   key = 16s + 8(j>>2) + 4(lane>>5) + (j&3) for element j; the A operand V^T is
+//   read from the row-major V tile with the transposing LDS read
+//   ds_read_b64_tr_b16 in that same key order.  O^T again has the query on the
+//   lane, so the per-row rescale and the final 1/l are per-lane scalars.
+//
+// LDS images (bank-conflict-free for the reads that use them)
+//   K tile [64][D]: 16-byte chunk c of row r at  r*2D + 16*(c ^ swzK(r))   (ds_read_b128 rows)
+//   V tile [64][D]: chunk c of row r at          r*2D + 16*(c ^ swzV(r))   (transposing reads)
+#include "myfa_common.h"
+
+namespace myfa {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mma;
+template <> struct Mma<__bf16> {
+    using vec8 = bf16x8;
+    using vec4 = bf16x4;
+    static __device__ __forceinline__ f32x16 run(s16x8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vec8, a), b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<_Float16> {
+    using vec8 = f16x8;
+    using vec4 = f16x4;
+    static __device__ __forceinline__ f32x16 run(s16x8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vec8, a), b, c, 0, 0, 0);
+    }
+};
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ s16x4 lds_read_tr(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+}
+
+// max(x[lane], x[lane ^ 32]) / sum, in every lane
+__device__ __forceinline__ float half_exchange_max(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+__device__ __forceinline__ float half_exchange_sum(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+
+template <int D> __device__ __forceinline__ int k_off(int row, int ch) {
+    if constexpr (D == 128) return row * 256 + ((ch ^ (row & 15)) << 4);
+    else                    return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
+}
+template <int D> __device__ __forceinline__ int v_off(int row, int ch) {
+    if constexpr (D == 128) return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
+    else                    return row * 128 + ((ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))) << 4);
+}
+
+constexpr int kWaves = 8;
+constexpr int kThreads = kWaves * 64;
+constexpr int kBQ = kWaves * 32;   // query rows per workgroup
+constexpr int kBKV = 64;           // keys per tile
+
+template <typename T, int D>
+__global__ void __launch_bounds__(kThreads, 2)
+attn_fwd_mfma_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* __restrict__ Vg,
+                     T* __restrict__ Og, float* __restrict__ LSEg, int N, int nqblk, int nwg, float sl2) {
+    using M = Mma<T>;
+    using vec8 = typename M::vec8;
+    using vec4 = typename M::vec4;
+    constexpr int CPR = D / 8;                   // 16-byte chunks per row
+    constexpr int TILE_B = kBKV * D * 2;         // bytes per K (or V) tile
+    constexpr int KS = D / 16;                   // k-steps of S^T = K Q^T
+    constexpr int DB = D / 32;                   // 32-row blocks of O^T
+    constexpr int LPT = kBKV * CPR / kThreads;   // 16-byte loads per thread per tile
+    static_assert(LPT >= 1, "tile smaller than one load per thread");
+
+    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_B];   // K0 K1 V0 V1
+
+    // Workgroups that share one head's K/V get consecutive logical ids, and the
+    // remap hands each XCD (blockIdx % 8 under round-robin dispatch) a contiguous
+    // range of logical ids, so a head's K/V stay in one XCD's L2.  Speed only.
+    int lid;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, qq = nwg >> 3, rr = nwg & 7;
+        lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int head = lid / nqblk;
+    const int q0 = (lid - head * nqblk) * kBQ;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    const size_t hoff = (size_t)head * (size_t)N * D;
+    const T* Qh = Qg + hoff;
+    const T* Kh = Kg + hoff;
+    const T* Vh = Vg + hoff;
+
+    // ---- Q^T fragments: lane (r, h) holds Q[row][16ks + 8h .. +7] for ks = 0..KS-1
+    const int qrow = q0 + wave * 32 + r;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+    vec8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        qf[ks] = *reinterpret_cast<const vec8*>(Qh + (size_t)qrow_c * D + 16 * ks + 8 * h);
+
+    // ---- staging of one K/V tile through registers
+    u32x4 kst[LPT], vst[LPT];
+    auto stage_load = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int id = tid + kThreads * i;
+            const int row = id / CPR, ch = id % CPR;
+            int g = kv0 + row;
+            g = g < N ? g : N - 1;                // tail rows: any valid row; masked later
+            kst[i] = *reinterpret_cast<const u32x4*>(Kh + (size_t)g * D + ch * 8);
+            vst[i] = *reinterpret_cast<const u32x4*>(Vh + (size_t)g * D + ch * 8);
+        }
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int id = tid + kThreads * i;
+            const int row = id / CPR, ch = id % CPR;
+            *reinterpret_cast<u32x4*>(lds + buf * TILE_B + k_off<D>(row, ch)) = kst[i];
+            *reinterpret_cast<u32x4*>(lds + (2 + buf) * TILE_B + v_off<D>(row, ch)) = vst[i];
+        }
+    };
+
+    f32x16 o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+    float m = -INFINITY;   // running row max of scale*log2(e)*S
+    float l = 0.f;         // this lane half's share of the running row sum
+
+    const int ntiles = (N + kBKV - 1) / kBKV;
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+
+    // lane-constant parts of the transposing-read address
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        const int kv0 = t * kBKV;
+        if (t + 1 < ntiles) stage_load(kv0 + kBKV);
+
+        const char* Kb = lds + buf * TILE_B;
+        const char* Vb = lds + (2 + buf) * TILE_B;
+
+        // ---- S^T = K Q^T : 2 key blocks x KS k-steps
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const s16x8 a = *reinterpret_cast<const s16x8*>(Kb + k_off<D>(32 * kb + r, 2 * ks + h));
+                s[kb] = M::run(a, qf[ks], s[kb]);
+            }
+        }
+
+        // ---- mask keys past N (last tile only)
+        if (kv0 + kBKV > N) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kv0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= N) s[kb][i] = -INFINITY;
+                }
+        }
+
+        // ---- online softmax (per query = per lane, two halves cooperate)
+        float tmax = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, s[kb][i]);
+        tmax = half_exchange_max(tmax);
+        const float m_new = fmaxf(m, tmax * sl2);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        m = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                s[kb][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], sl2, -m_new));
+                psum += s[kb][i];
+            }
+        l = l * alpha + psum;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+
+        // ---- O^T += V^T P^T : 4 k-steps of 16 keys x DB row blocks
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                vec8 pb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[j] = (T)s[kb][8 * st + j];
+                const int r0 = 32 * kb + 16 * st + 4 * h + tq;   // key row of the first 4-row block
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const int ch = 4 * db + 2 * tg1 + (tp >> 1);
+                    const s16x4 lo = lds_read_tr(Vb + v_off<D>(r0, ch) + 8 * (tp & 1));
+                    const s16x4 hi = lds_read_tr(Vb + v_off<D>(r0 + 8, ch) + 8 * (tp & 1));
+                    s16x8 a;
+                    a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
+                    a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
+                    o[db] = M::run(a, pb, o[db]);
+                }
+            }
+
+        // ---- publish the next tile: its buffer was last read before the previous barrier
+        if (t + 1 < ntiles) stage_write(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: O = O^T / l, written as rows; lane (r,h) holds, for its query,
+    // d = 32db + 8g + 4h + (0..3) in registers 4g..4g+3 of block db
+    const float ltot = half_exchange_sum(l);
+    const float inv = 1.0f / ltot;
+    if (qrow < N) {
+        T* orow = Og + hoff + (size_t)qrow * D;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                vec4 w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = (T)(o[db][4 * g + j] * inv);
+                *reinterpret_cast<vec4*>(orow + 32 * db + 8 * g + 4 * h) = w;
+            }
+        if (LSEg != nullptr && h == 0)
+            LSEg[(size_t)head * N + qrow] = (m + __builtin_amdgcn_logf(ltot)) * 0.6931471805599453f;
+    }
+}
+
+template <typename T, int D>
+int launch(const void* q, const void* k, const void* v, void* o, float* lse,
+           int64_t heads, int64_t N, float scale, hipStream_t s) {
+    const int64_t nqblk = cdiv(N, kBQ);
+    const int64_t nwg = heads * nqblk;
+    if (nwg > 0x7fffffffLL) return fail(MYFA_E_UNSUPPORTED, "attention: too many workgroups (%lld)", (long long)nwg);
+    const float sl2 = scale * 1.4426950408889634f;
+    hipLaunchKernelGGL((attn_fwd_mfma_kernel<T, D>), dim3((unsigned)nwg), dim3(kThreads), 0, s,
+                       static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
+                       static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2);
+    return check_launch("attn_fwd_mfma");
+}
+
+}  // namespace
+
+// dtype: MYFA_F16 or MYFA_BF16; d: 64 or 128; heads = B*H
+int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* lse,
+                  int64_t heads, int64_t N, int64_t d, float scale, int dtype, hipStream_t s) {
+    if (!(scale > 0.f)) return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16): scale must be > 0, got %g", (double)scale);
+    if (N > 0x7fffffffLL / 256) return fail(MYFA_E_UNSUPPORTED, "attention: N=%lld too large", (long long)N);
+    if (dtype == MYFA_BF16 && d == 128) return launch<__bf16, 128>(q, k, v, o, lse, heads, N, scale, s);
+    if (dtype == MYFA_BF16 && d == 64)  return launch<__bf16, 64>(q, k, v, o, lse, heads, N, scale, s);
+    if (dtype == MYFA_F16 && d == 128)  return launch<_Float16, 128>(q, k, v, o, lse, heads, N, scale, s);
+    if (dtype == MYFA_F16 && d == 64)   return launch<_Float16, 64>(q, k, v, o, lse, heads, N, scale, s);
+    return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16): head dim %lld not in {64, 128}", (long long)d);
+}
+
+}  // namespace myfa

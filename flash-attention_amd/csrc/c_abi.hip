@@ -1,0 +1,102 @@
+// extern "C" surface of libmyfa_gfx950.so (declared in include/myfa.h).
+//
+// Replaces the argument checking / dispatch half of the reference's binding
+// layer (csrc/api.cpp:110-192); output allocation stays with the caller.
+#include "myfa_common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace myfa {
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MYFA_E_LAUNCH, "%s: launch failed: %s", what, hipGetErrorString(e));
+    return MYFA_OK;
+}
+
+// implemented in the kernel translation units
+int softmax_f32(const float* in, float* out, int64_t h, int64_t w, hipStream_t s);
+int attn_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse,
+                 int64_t heads, int64_t N, int64_t d, int64_t k_key_stride, int64_t k_d_stride,
+                 float scale, hipStream_t s);
+int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* lse,
+                  int64_t heads, int64_t N, int64_t d, float scale, int dtype, hipStream_t s);
+
+}  // namespace myfa
+
+using namespace myfa;
+
+extern "C" {
+
+int myfa_abi_version(void) { return MYFA_ABI_VERSION; }
+
+const char* myfa_last_error(void) { return g_err; }
+
+int myfa_device_info(int device, int* cu_count, int* lds_bytes, int* wave_size, char* arch, int arch_len) {
+    hipDeviceProp_t p;
+    const hipError_t e = hipGetDeviceProperties(&p, device);
+    if (e != hipSuccess) return fail(MYFA_E_DEVICE, "device %d: %s", device, hipGetErrorString(e));
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (lds_bytes) *lds_bytes = (int)p.sharedMemPerBlock;
+    if (wave_size) *wave_size = p.warpSize;
+    if (arch && arch_len > 0) {
+        std::strncpy(arch, p.gcnArchName, (size_t)arch_len - 1);
+        arch[arch_len - 1] = '\0';
+    }
+    return MYFA_OK;
+}
+
+int myfa_softmax_f32(const float* in, float* out, int64_t h, int64_t w, void* stream) {
+    return softmax_f32(in, out, h, w, static_cast<hipStream_t>(stream));
+}
+
+int myfa_attn_fwd_f32(const float* q, const float* k_t, const float* v, float* o,
+                      int64_t n, int64_t d, float scale, void* stream) {
+    if (n < 0 || d < 0) return fail(MYFA_E_INVALID, "attention: negative size n=%lld d=%lld", (long long)n, (long long)d);
+    if (n == 0 || d == 0) return MYFA_OK;
+    if (!q || !k_t || !v || !o) return fail(MYFA_E_INVALID, "attention: null pointer");
+    // K_t is [d, n]: key stride 1, dim stride n
+    return attn_fwd_f32(q, k_t, v, o, nullptr, 1, n, d, 1, n, scale, static_cast<hipStream_t>(stream));
+}
+
+int myfa_attn_fwd_bhnd(const void* q, const void* k, const void* v, void* o, float* lse,
+                       int64_t B, int64_t H, int64_t N, int64_t d, float scale, int dtype, void* stream) {
+    if (B < 0 || H < 0 || N < 0 || d < 0)
+        return fail(MYFA_E_INVALID, "attention: negative size B=%lld H=%lld N=%lld d=%lld",
+                    (long long)B, (long long)H, (long long)N, (long long)d);
+    if (B == 0 || H == 0 || N == 0 || d == 0) return MYFA_OK;
+    if (!q || !k || !v || !o) return fail(MYFA_E_INVALID, "attention: null pointer");
+    const int64_t heads = B * H;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case MYFA_F32:
+            // K is [N, d]: key stride d, dim stride 1
+            return attn_fwd_f32(static_cast<const float*>(q), static_cast<const float*>(k),
+                                static_cast<const float*>(v), static_cast<float*>(o), lse,
+                                heads, N, d, d, 1, scale, s);
+        case MYFA_F16:
+        case MYFA_BF16:
+            if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) |
+                 reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(o)) % 16 != 0)
+                return fail(MYFA_E_INVALID, "attention (f16/bf16): tensors must be 16-byte aligned");
+            return attn_fwd_mfma(q, k, v, o, lse, heads, N, d, scale, dtype, s);
+        default:
+            return fail(MYFA_E_INVALID, "attention: unknown dtype tag %d", dtype);
+    }
+}
+
+}  // extern "C"

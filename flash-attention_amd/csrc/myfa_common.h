@@ -1,0 +1,60 @@
+// Shared host/device helpers for libmyfa_gfx950.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "myfa.h"
+
+namespace myfa {
+
+// Records a message for myfa_last_error() and returns `code`.
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// Peeks at the launch status of the kernel just enqueued (no synchronisation).
+int check_launch(const char* what);
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+__host__ __device__ constexpr int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- wave64 reductions on DPP / ds_swizzle (no LDS traffic, no shuffles) ----
+// Steps: xor-1 and xor-2 inside each quad (quad_perm), mirror inside 8 and inside
+// 16 lanes (row_half_mirror, row_mirror), swap the 16-lane rows inside each half
+// (ds_swizzle bit mode, xor 0x10), then combine the two 32-lane halves through
+// readlane.  The result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+__device__ __forceinline__ float swizzle_xor16(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+}
+
+__device__ __forceinline__ float read_lane(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+struct MaxOp {
+    __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); }
+};
+struct SumOp {
+    __device__ __forceinline__ float operator()(float a, float b) const { return a + b; }
+};
+
+template <typename Op>
+__device__ __forceinline__ float wave_reduce(float x, Op op) {
+    x = op(x, dpp_mov<0xB1>(x));   // quad_perm [1,0,3,2]
+    x = op(x, dpp_mov<0x4E>(x));   // quad_perm [2,3,0,1]
+    x = op(x, dpp_mov<0x141>(x));  // row_half_mirror
+    x = op(x, dpp_mov<0x140>(x));  // row_mirror
+    x = op(x, swizzle_xor16(x));
+    return op(read_lane(x, 0), read_lane(x, 32));
+}
+
+__device__ __forceinline__ float wave_max(float x) { return wave_reduce(x, MaxOp{}); }
+__device__ __forceinline__ float wave_sum(float x) { return wave_reduce(x, SumOp{}); }
+
+}  // namespace myfa

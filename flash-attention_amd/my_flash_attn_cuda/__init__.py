@@ -1,0 +1,156 @@
+"""Drop-in for the reference's ``my_flash_attn_cuda`` extension, on MI355X.
+
+Same module name and the same five functions the reference registers with
+pybind (csrc/api.cpp:194-200):
+
+    my_softmax(inp, kernel_no)      my_attention(Q, K_t, V)
+    my_matmul(A, B)   my_matmul_cublas(A, B)   my_matmul_out(out, A, B)
+
+plus the batched forward the reference sketches but never wrote
+(csrc/my_flash_attn/flash_attention.cu:23-69):
+
+    flash_attn_fwd(q, k, v, scale=1.0, return_lse=False)     # (B, H, N, d)
+
+The host side is Python: it validates arguments the way the reference's C++
+does (CHECK_INPUT = device tensor + contiguous, csrc/my_flash_attn/util.hpp:7-9;
+size checks, csrc/api.cpp:18,45,73,182-183; failures surface as RuntimeError,
+which is what TORCH_CHECK raises through pybind), allocates the output with
+torch, and calls the HIP kernels through the C ABI in ``include/myfa.h`` on
+torch's *current* stream.  There is no CPU path: tensors must live on the GPU.
+"""
+import torch
+
+from . import _lib
+from ._lib import MYFA_BF16, MYFA_F16, MYFA_F32, device_info  # noqa: F401
+
+__all__ = ["my_softmax", "my_attention", "my_matmul", "my_matmul_cublas", "my_matmul_out",
+           "flash_attn_fwd", "device_info"]
+
+_DTYPE_TAG = {torch.float32: MYFA_F32, torch.float16: MYFA_F16, torch.bfloat16: MYFA_BF16}
+
+
+def _check_input(x, name):
+    # CHECK_CUDA / CHECK_CONTIGUOUS (util.hpp:7-9)
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not x.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not x.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+
+
+def _check_float(x, name):
+    # the reference reads data_ptr<float>(), which rejects every other dtype
+    if x.dtype != torch.float32:
+        raise RuntimeError(f"expected scalar type Float but found {x.dtype} for {name}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def my_softmax(inp, kernel_no=1):
+    """Row softmax of a 2-D float32 tensor; returns a new tensor.
+
+    Mirrors my_softmax (csrc/api.cpp:110-166).  The reference's kernel_no picks
+    one of five implementations of the same function (three of which its own
+    checks reject, api.cpp:130,135,140); here 1..5 all run the one HIP kernel,
+    and any other number raises like api.cpp:158.
+    """
+    _check_input(inp, "inp")
+    _check_float(inp, "inp")
+    if inp.dim() != 2:
+        raise RuntimeError(f"my_softmax expects a 2-D tensor, got {inp.dim()}-D")
+    if kernel_no not in (1, 2, 3, 4, 5):
+        raise RuntimeError(f"Unsupported kernel number: {kernel_no}")
+    h, w = inp.shape
+    out = torch.empty_like(inp)   # every element is written; no zero-fill pass
+    with torch.cuda.device(inp.device):
+        _lib.check(_lib.lib.myfa_softmax_f32(inp.data_ptr(), out.data_ptr(), h, w, _stream()))
+    return out
+
+
+def my_attention(Q, K, V):
+    """softmax(Q @ K) @ V for float32 Q:(n,d), K:(d,n) -- already transposed -- and V:(n,d).
+
+    Mirrors my_attention (csrc/api.cpp:168-192): unscaled logits, no mask.  One
+    fused kernel instead of SGEMM -> softmax -> SGEMM.
+    """
+    _check_input(Q, "Q"); _check_input(K, "K"); _check_input(V, "V")
+    for t, name in ((Q, "Q"), (K, "K"), (V, "V")):
+        _check_float(t, name)
+        if t.dim() != 2:
+            raise RuntimeError("Wrong sizes!")
+    n, d = Q.shape
+    if not (K.shape[0] == d and K.shape[1] == n and V.shape[0] == n and V.shape[1] == d):
+        raise RuntimeError("Wrong sizes!")
+    out = torch.empty_like(Q)
+    with torch.cuda.device(Q.device):
+        _lib.check(_lib.lib.myfa_attn_fwd_f32(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(),
+                                              n, d, 1.0, _stream()))
+    return out
+
+
+def flash_attn_fwd(q, k, v, scale=1.0, return_lse=False):
+    """Batched attention forward: softmax(scale * q @ k^T) @ v per (batch, head).
+
+    q, k, v: contiguous (B, H, N, d) GPU tensors of one dtype (float16, bfloat16
+    or float32); k is NOT transposed.  scale defaults to 1.0, the reference's
+    semantics (its tests compare against scaled_dot_product_attention(scale=1.0),
+    tests/test_flash_attn.py:165,183); pass d ** -0.5 for the usual scaling.
+    float16/bfloat16 run on the matrix cores and need d in {64, 128}.
+    With return_lse=True also returns the float32 (B, H, N) row log-sum-exp of the
+    scaled logits (the m + log l statistic of tests/test_flash_attn.py:58-59,98-99).
+    """
+    _check_input(q, "q"); _check_input(k, "k"); _check_input(v, "v")
+    if q.dim() != 4:
+        raise RuntimeError(f"flash_attn_fwd expects (B, H, N, d) tensors, got {q.dim()}-D")
+    if not (q.shape == k.shape == v.shape):
+        raise RuntimeError("Wrong sizes!")
+    if not (q.dtype == k.dtype == v.dtype):
+        raise RuntimeError("Scalar type mismatch!")
+    if q.dtype not in _DTYPE_TAG:
+        raise RuntimeError(f"unsupported dtype {q.dtype}")
+    B, H, N, d = q.shape
+    out = torch.empty_like(q)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=q.device) if return_lse else None
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.lib.myfa_attn_fwd_bhnd(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+            lse.data_ptr() if return_lse else None,
+            B, H, N, d, float(scale), _DTYPE_TAG[q.dtype], _stream()))
+    return (out, lse) if return_lse else out
+
+
+# ---- the matmul trio ---------------------------------------------------------
+# Not on the softmax/attention path.  The reference's 16x16-tile kernel
+# (csrc/my_flash_attn/matmul.cu:22-50) and its cuBLAS wrapper (csrc/api.cpp:68-105)
+# are kept as names with the reference's checks; the product itself is
+# torch.matmul, i.e. the vendor GEMM of this platform, as the reference's
+# my_matmul_cublas is the vendor GEMM of its platform.
+
+def _matmul_checks(A, B):
+    _check_input(A, "A"); _check_input(B, "B")
+    if A.dim() != 2 or B.dim() != 2 or A.shape[1] != B.shape[0]:
+        raise RuntimeError("Size mismatch!")
+
+
+def my_matmul(A, B):
+    _matmul_checks(A, B)
+    return torch.matmul(A, B)
+
+
+def my_matmul_cublas(A, B):
+    _matmul_checks(A, B)
+    return torch.matmul(A, B)
+
+
+def my_matmul_out(out, A, B):
+    _check_input(out, "out")
+    _matmul_checks(A, B)
+    if tuple(out.shape) != (A.shape[0], B.shape[1]):
+        raise RuntimeError("Size mismatch!")
+    if not (out.dtype == A.dtype == B.dtype):
+        raise RuntimeError("Scalar type mismatch!")
+    torch.matmul(A, B, out=out)
+    return out

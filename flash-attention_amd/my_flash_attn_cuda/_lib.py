@@ -1,0 +1,69 @@
+"""ctypes loader for libmyfa_gfx950.so (the C ABI declared in include/myfa.h).
+
+There is deliberately no fallback: if the shared library is missing or does not
+export the expected ABI, importing the package fails.  Build it with
+``python flash-attention_amd/build.py`` (or ``__graft_entry__.build()``).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmyfa_gfx950.so")
+
+ABI_VERSION = 1
+MYFA_F32, MYFA_F16, MYFA_BF16 = 0, 1, 2
+
+# every symbol include/myfa.h declares
+EXPORTS = (
+    "myfa_abi_version",
+    "myfa_last_error",
+    "myfa_device_info",
+    "myfa_softmax_f32",
+    "myfa_attn_fwd_f32",
+    "myfa_attn_fwd_bhnd",
+)
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the MI355X kernels are not built. "
+            "Run `python flash-attention_amd/build.py` (needs hipcc); there is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i64, f32, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_int
+    lib.myfa_abi_version.argtypes = []
+    lib.myfa_abi_version.restype = ci
+    lib.myfa_last_error.argtypes = []
+    lib.myfa_last_error.restype = ctypes.c_char_p
+    lib.myfa_device_info.argtypes = [ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci),
+                                     ctypes.c_char_p, ci]
+    lib.myfa_device_info.restype = ci
+    lib.myfa_softmax_f32.argtypes = [vp, vp, i64, i64, vp]
+    lib.myfa_softmax_f32.restype = ci
+    lib.myfa_attn_fwd_f32.argtypes = [vp, vp, vp, vp, i64, i64, f32, vp]
+    lib.myfa_attn_fwd_f32.restype = ci
+    lib.myfa_attn_fwd_bhnd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, ci, vp]
+    lib.myfa_attn_fwd_bhnd.restype = ci
+    got = lib.myfa_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {got}, this package expects {ABI_VERSION}; rebuild")
+    return lib
+
+
+lib = _load()
+
+
+def check(status):
+    """Turns a nonzero C status into RuntimeError (what the reference's TORCH_CHECK
+    failures surface as in Python)."""
+    if status != 0:
+        msg = lib.myfa_last_error().decode("utf-8", "replace")
+        raise RuntimeError(msg or f"libmyfa error {status}")
+
+
+def device_info(device=0):
+    cu, lds, wave = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    arch = ctypes.create_string_buffer(64)
+    check(lib.myfa_device_info(int(device), ctypes.byref(cu), ctypes.byref(lds), ctypes.byref(wave), arch, 64))
+    return {"cu_count": cu.value, "lds_bytes": lds.value, "wave_size": wave.value,
+            "arch": arch.value.decode()}

@@ -1,0 +1,110 @@
+/*
+ * myfa.h -- C ABI of libmyfa_gfx950.so: row-softmax and attention-forward for
+ * AMD Instinct MI355X (gfx950 / CDNA4).
+ *
+ * This is the drop-in boundary.  It replaces the C++/pybind layer of the
+ * reference (csrc/api.cpp) for the softmax/attention path: each entry point
+ * below names the reference interface it stands in for.  Signatures are plain
+ * C: device pointers, sizes, a scale and a HIP stream handle (hipStream_t passed
+ * as void*; NULL = the default stream).  No torch types.
+ *
+ * Conventions
+ *   - Every function returns 0 on success and a nonzero MYFA_E_* code on
+ *     failure; myfa_last_error() then returns a thread-local, human-readable
+ *     message.  The library never calls exit() (the reference's cuBLAS/CUDA
+ *     helpers do: csrc/my_flash_attn/cublas.hpp:6-12, util.hpp:10-20).
+ *   - All pointers are device pointers on the current HIP device; tensors are
+ *     dense row-major ("contiguous", the reference's CHECK_CONTIGUOUS,
+ *     csrc/my_flash_attn/util.hpp:8).  The library owns nothing: the caller
+ *     allocates inputs and outputs (the reference allocates outputs with
+ *     torch::zeros, csrc/api.cpp:46,74,114; here the Python host layer does).
+ *   - Launches are asynchronous on `stream`; nothing synchronises.  (The
+ *     reference launches on the legacy default stream,
+ *     csrc/my_flash_attn/softmax.cu:463-475.)
+ *   - No entry point allocates or frees device memory.
+ */
+#ifndef MYFA_H_
+#define MYFA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MYFA_ABI_VERSION 1
+
+enum {
+    MYFA_OK = 0,
+    MYFA_E_INVALID = 1,     /* bad argument (null pointer, negative size, ...) */
+    MYFA_E_UNSUPPORTED = 2, /* shape / dtype outside what the kernels cover    */
+    MYFA_E_LAUNCH = 3,      /* HIP reported an error at launch                 */
+    MYFA_E_DEVICE = 4       /* no usable gfx950 device                         */
+};
+
+/* dtype tags for the batched attention entry point */
+enum { MYFA_F32 = 0, MYFA_F16 = 1, MYFA_BF16 = 2 };
+
+/* Library / ABI identification (no reference counterpart; used by the host
+ * layer to check that header and .so agree). */
+int myfa_abi_version(void);
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* myfa_last_error(void);
+
+/* Fills in facts about HIP device `device`: CU count, LDS bytes per workgroup,
+ * wavefront size, and the gcnArchName (NUL-terminated, truncated to arch_len).
+ * Any out-pointer may be NULL. */
+int myfa_device_info(int device, int* cu_count, int* lds_bytes, int* wave_size,
+                     char* arch, int arch_len);
+
+/*
+ * Row softmax of a dense [h, w] float matrix: out[r, :] = softmax(in[r, :]).
+ *
+ * Replaces my_softmax(inp, kernel_no) -> launch_softmax_kernel<128> ->
+ * softmax_kernel_1..5 (csrc/api.cpp:110-166, csrc/my_flash_attn/softmax.cu:20-487).
+ * All five kernel numbers of the reference compute the same function; there is
+ * one implementation here, so kernel_no is handled (validated) by the host
+ * layer and does not cross this boundary.  `in` and `out` may not overlap
+ * unless identical (in-place is allowed).  h == 0 or w == 0 is a no-op.
+ */
+int myfa_softmax_f32(const float* in, float* out, int64_t h, int64_t w, void* stream);
+
+/*
+ * 2-D single-head attention, float32, the reference's calling convention:
+ *     o = softmax(scale * (q @ k_t)) @ v
+ * q: [n, d]; k_t: [d, n] (K already transposed, as the reference's caller
+ * passes it, tests/test_flash_attn.py:163); v: [n, d]; o: [n, d].
+ *
+ * Replaces my_attention(Q, K, V) = my_matmul_cublas -> my_softmax ->
+ * my_matmul_cublas (csrc/api.cpp:168-192) with one fused kernel.  The
+ * reference has no scale argument (logits are unscaled); pass scale = 1.0f for
+ * its semantics.
+ */
+int myfa_attn_fwd_f32(const float* q, const float* k_t, const float* v, float* o,
+                      int64_t n, int64_t d, float scale, void* stream);
+
+/*
+ * Batched multi-head attention forward, no mask, no dropout:
+ *     o[b,h] = softmax(scale * q[b,h] @ k[b,h]^T) @ v[b,h]
+ * q, k, v, o: dense [B, H, N, d] of `dtype` (MYFA_F32 / MYFA_F16 / MYFA_BF16);
+ * k is NOT transposed.  Softmax statistics and both accumulations are float32.
+ * If `lse` is non-NULL it receives the row log-sum-exp (natural log) of the
+ * scaled logits as float32 [B, H, N].
+ *
+ * This is the fused forward the reference sketches but never wrote
+ * (csrc/my_flash_attn/flash_attention.cu:23-69: kernel signature
+ * (out, Q, K, V, seq_len, d_head), host wrapper allocating out, l, m); its
+ * math is the reference's Python Algorithm-1 restatement
+ * (tests/test_flash_attn.py:46-101) applied per (batch, head).
+ * MYFA_F16 / MYFA_BF16 run on MFMA and require d in {64, 128}; MYFA_F32 accepts
+ * any d >= 1.
+ */
+int myfa_attn_fwd_bhnd(const void* q, const void* k, const void* v, void* o, float* lse,
+                       int64_t B, int64_t H, int64_t N, int64_t d,
+                       float scale, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MYFA_H_ */

@@ -1,0 +1,94 @@
+"""CPU tests: the oracle against the golden vectors made from the reference.
+
+The fixtures in tests/golden/ hold the reference's own outputs
+(tests/test_flash_attn.py: _softmax, _attention_forward, _flash_attention_forward)
+and the PyTorch ops its tests compare against, on the shapes those tests use.
+The reference computes in float32, so at N ~ 1000 its result is ~1e-5 from the
+exact one; the oracle (float64) is held to 5e-5 of it, and the reference's own
+test tolerance is 1e-4 (tests/test_flash_attn.py:151,168,186).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden
+from oracle import ref_cpu
+
+ATTN = [(2, 2), (1, 1), (2, 20), (2, 99), (20, 2), (99, 20), (1024, 64), (1023, 63), (1025, 65), (128, 64)]
+SOFTMAX = [(255, 516), (1024, 1024)]
+PIN_TOL = 5e-5
+
+
+def test_manifest_records_pinning():
+    with open(os.path.join(GOLDEN, "MANIFEST.json")) as f:
+        man = json.load(f)
+    assert set(man["attention"]) == {f"attn_{n}x{d}" for n, d in ATTN}
+    for rec in man["attention"].values():
+        assert rec["oracle_np_vs_ref_naive"] <= PIN_TOL
+        assert rec["oracle_alg1_vs_ref_flash"] <= PIN_TOL
+        assert rec["oracle_c_vs_ref_naive"] <= PIN_TOL
+        # the reference's two paths agree with SDPA to its own tolerance
+        assert rec["ref_naive_vs_sdpa"] < 1e-4 and rec["ref_flash_vs_sdpa"] < 1e-4
+    for rec in man["softmax"].values():
+        assert rec["oracle_np_vs_ref"] <= 1e-6 and rec["oracle_c_vs_ref"] <= 1e-6
+
+
+@pytest.mark.parametrize("h,w", SOFTMAX)
+def test_softmax_oracles_vs_golden(h, w, c_oracle):
+    g = load_golden(f"softmax_{h}x{w}")
+    x = g["x"]
+    for out in (ref_cpu.softmax_rows(x), c_oracle.softmax_rows(x), c_oracle.softmax_rows(x, f32_arith=True)):
+        assert np.abs(out - g["out_ref"]).max() <= 1e-6
+        assert np.abs(out - g["out_torch"]).max() <= 1e-6
+        assert np.allclose(out.sum(axis=1), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,d", ATTN)
+def test_attention_oracles_vs_golden(n, d, c_oracle):
+    g = load_golden(f"attn_{n}x{d}")
+    q, k, v = g["q"], g["k"], g["v"]
+    naive = ref_cpu.attention_naive(q, k, v)
+    alg1, l, m = ref_cpu.attention_flash_alg1(q, k, v)
+    fa2 = ref_cpu.attention_flash_fa2(q, k, v)
+    cc = c_oracle.attention(q, k, v)
+    for out in (naive, alg1, fa2, cc):
+        assert out.shape == (n, d)
+        assert np.abs(out - g["out_ref_naive"]).max() <= PIN_TOL
+        assert np.abs(out - g["out_ref_flash"]).max() <= PIN_TOL
+        assert np.abs(out - g["out_sdpa"]).max() <= PIN_TOL
+    # the float64 restatements agree with each other far more tightly
+    assert np.abs(naive - alg1).max() < 1e-12
+    assert np.abs(naive - fa2).max() < 1e-12
+    assert np.abs(naive - cc).max() < 1e-6          # C oracle rounds its result to float32
+    # Algorithm-1 statistics: m + log(l) is the row log-sum-exp
+    lse = ref_cpu.attention_lse(q, k)
+    assert np.abs((m + np.log(l)) - lse).max() < 1e-10
+
+
+def test_flash_block_sizes_match_reference_formula():
+    # Bc = ceil(64 KiB / 4d), Br = min(Bc, d)  (tests/test_flash_attn.py:53-55)
+    assert ref_cpu.flash_block_sizes(64) == (64, 256)
+    assert ref_cpu.flash_block_sizes(128) == (128, 128)
+    assert ref_cpu.flash_block_sizes(1) == (1, 16384)
+    assert ref_cpu.flash_block_sizes(99) == (99, 166)
+
+
+def test_bhnd_oracle_matches_per_head_naive():
+    rng = np.random.default_rng(0)
+    q, k, v = (rng.standard_normal((2, 3, 37, 16)).astype(np.float32) for _ in range(3))
+    out = ref_cpu.attention_bhnd(q, k, v, scale=0.25)
+    for b in range(2):
+        for h in range(3):
+            ref = ref_cpu.attention_naive(q[b, h], k[b, h], v[b, h], scale=0.25)
+            assert np.abs(out[b, h] - ref).max() < 1e-12
+
+
+def test_c_oracle_query_row_sample(c_oracle):
+    rng = np.random.default_rng(1)
+    q, k, v = (rng.standard_normal((2, 50, 24)).astype(np.float32) for _ in range(3))
+    full = c_oracle.attention(q, k, v, scale=0.5)
+    rows = np.array([0, 7, 49])
+    part = c_oracle.attention(q[:, rows], k, v, scale=0.5)
+    assert np.array_equal(part, full[:, rows])
