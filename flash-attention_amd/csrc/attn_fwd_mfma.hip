@@ -67,16 +67,25 @@ __device__ __forceinline__ s16x4 lds_read_tr(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
 }
 
-// max(x[lane], x[lane ^ 32]) / sum, in every lane
-__device__ __forceinline__ float half_exchange_max(float x) {
+// Both lane halves' values of x, in every lane: {x[lane & 31], x[(lane & 31) + 32]}.
+// v_permlane32_swap exchanges the upper half of its first operand with the lower
+// half of its second.  The two results are copied out of the builtin's vector
+// before any bit_cast: __builtin_bit_cast applied directly to an element of that
+// vector reads element 0 for every index (hipcc 7.2).
+struct HalfPair { float lo, hi; };
+__device__ __forceinline__ HalfPair both_halves(float x) {
     const unsigned u = __builtin_bit_cast(unsigned, x);
-    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned a = r[0], b = r[1];
+    return {__builtin_bit_cast(float, a), __builtin_bit_cast(float, b)};
+}
+__device__ __forceinline__ float half_exchange_max(float x) {
+    const HalfPair p = both_halves(x);
+    return fmaxf(p.lo, p.hi);
 }
 __device__ __forceinline__ float half_exchange_sum(float x) {
-    const unsigned u = __builtin_bit_cast(unsigned, x);
-    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+    const HalfPair p = both_halves(x);
+    return p.lo + p.hi;
 }
 
 template <int D> __device__ __forceinline__ int k_off(int row, int ch) {
