@@ -33,6 +33,8 @@
 //   V tile [64][D]: chunk c of row r at          r*2D + 16*(c ^ swzV(r))   (transposing reads)
 #include "myfa_common.h"
 
+#include <cstdlib>
+
 namespace myfa {
 namespace {
 
@@ -189,7 +191,9 @@ attn_fwd_mfma_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         const int kv0 = t * kBKV;
-        if (t + 1 < ntiles) stage_load(kv0 + kBKV);
+        // Always issued (the row index is clamped inside): a load under a condition makes
+        // hipcc guard the staging registers with conservative s_waitcnt vmcnt(0).
+        stage_load(kv0 + kBKV);
 
         const char* Kb = lds + buf * TILE_B;
         const char* Vb = lds + (2 + buf) * TILE_B;
@@ -264,7 +268,7 @@ attn_fwd_mfma_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T
             }
 
         // ---- publish the next tile: its buffer was last read before the previous barrier
-        if (t + 1 < ntiles) stage_write(buf ^ 1);
+        stage_write(buf ^ 1);
         __syncthreads();
     }
 
@@ -288,6 +292,353 @@ attn_fwd_mfma_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Ping-pong variant.  Same tiles, LDS images and register choreography as the
+// kernel above, different schedule: the loop is software-pipelined into a
+// matrix phase  M(t) = { S(t+1) = K(t+1) Q^T ;  O += V(t)^T P(t)^T }  (32 MFMAs
+// back to back) and a vector phase  X(t+1) = { online softmax of S(t+1) -> P(t+1),
+// rescale O }, and the two waves that share a SIMD (wave w and wave w+4) run in
+// opposite phases, one barrier per phase: while waves 0-3 keep the matrix pipe
+// busy, waves 4-7 do their exponentials on the vector pipe, and vice versa.
+// Waves 4-7 simply run the same program one phase late.
+//
+// LDS hand-over with two K slots and two V slots: M(u) reads K(u+1), V(u) and
+// -- after its MFMAs -- publishes this thread's share of K(u+2) (into the slot
+// K(u) has left) and V(u+1); the global loads for those were issued one phase
+// earlier, in X(u).  Waves 0-3 run M(u) in phase 2u and waves 4-7 in phase 2u+1;
+// the readers of K(u+2)/V(u+1) are M(u+1) in phases 2u+2 / 2u+3, behind the
+// barrier that ends phase 2u+1; the data they replace was last read by M(u-1)
+// in phases 2u-2 / 2u-1.
+//
+// `thr` is the deferred-max threshold in log2 units: the running max only moves
+// (and O, l are only rescaled) in a tile where some row's max grew by more than
+// thr.  thr = 0 rescales whenever any max grew, which is exactly the textbook
+// recurrence; thr > 0 lets P reach 2^thr.
+// STAMP builds are diagnostic only: they bracket the phases with s_memtime and write the
+// per-phase cycle sums of waves 0 and 4 to `dbg` (8 u64 per workgroup); never timed.
+__device__ __forceinline__ unsigned long long stamp() {
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+template <typename T, int D, bool STAMP = false, int ABLATE = 0>
+__global__ void __launch_bounds__(kThreads, 2)
+attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* __restrict__ Vg,
+                        T* __restrict__ Og, float* __restrict__ LSEg, int N, int nqblk, int nwg,
+                        float sl2, float thr, unsigned long long* __restrict__ dbg = nullptr) {
+    using M = Mma<T>;
+    using vec8 = typename M::vec8;
+    using vec4 = typename M::vec4;
+    constexpr int CPR = D / 8;
+    constexpr int TILE_B = kBKV * D * 2;
+    constexpr int KS = D / 16;
+    constexpr int DB = D / 32;
+    constexpr int LPT = kBKV * CPR / kThreads;
+    static_assert(LPT >= 1, "tile smaller than one load per thread");
+
+    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_B];   // K0 K1 V0 V1
+
+    int lid;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, qq = nwg >> 3, rr = nwg & 7;
+        lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int head = lid / nqblk;
+    const int q0 = (lid - head * nqblk) * kBQ;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);   // 0: leads, 1: one phase behind
+    const int r = lane & 31, h = lane >> 5;
+
+    const size_t hoff = (size_t)head * (size_t)N * D;
+    const T* Qh = Qg + hoff;
+    const T* Kh = Kg + hoff;
+    const T* Vh = Vg + hoff;
+
+    const int qrow = q0 + wave * 32 + r;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+    vec8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        qf[ks] = *reinterpret_cast<const vec8*>(Qh + (size_t)qrow_c * D + 16 * ks + 8 * h);
+
+    // ---- register staging, K and V separately
+    u32x4 kst[LPT], vst[LPT];
+    auto load_tile = [&](u32x4 (&st)[LPT], const T* base, int tile) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int id = tid + kThreads * i;
+            const int row = id / CPR, ch = id % CPR;
+            int g = tile * kBKV + row;
+            g = g < N ? g : N - 1;            // past the end: any valid row (masked or never used)
+            st[i] = *reinterpret_cast<const u32x4*>(base + (size_t)g * D + ch * 8);
+        }
+    };
+    auto write_k = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int id = tid + kThreads * i;
+            *reinterpret_cast<u32x4*>(lds + slot * TILE_B + k_off<D>(id / CPR, id % CPR)) = kst[i];
+        }
+    };
+    auto write_v = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int id = tid + kThreads * i;
+            *reinterpret_cast<u32x4*>(lds + (2 + slot) * TILE_B + v_off<D>(id / CPR, id % CPR)) = vst[i];
+        }
+    };
+
+    f32x16 o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    f32x16 s[2];
+    vec8 pb[4];
+
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
+
+    auto qk = [&](int slot) {
+        const char* Kb = lds + slot * TILE_B;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const s16x8 a = *reinterpret_cast<const s16x8*>(Kb + k_off<D>(32 * kb + r, 2 * ks + h));
+                if constexpr (ABLATE & 1) { asm volatile("" :: "v"(a)); s[kb][ks] += 1.0f; }
+                else s[kb] = M::run(a, qf[ks], s[kb]);
+            }
+        }
+    };
+    auto pv = [&](int slot) {
+        const char* Vb = lds + (2 + slot) * TILE_B;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const int r0 = 32 * kb + 16 * st + 4 * h + tq;
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const int ch = 4 * db + 2 * tg1 + (tp >> 1);
+                    const s16x4 lo = lds_read_tr(Vb + v_off<D>(r0, ch) + 8 * (tp & 1));
+                    const s16x4 hi = lds_read_tr(Vb + v_off<D>(r0 + 8, ch) + 8 * (tp & 1));
+                    s16x8 a;
+                    a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
+                    a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
+                    if constexpr (ABLATE & 1) { asm volatile("" :: "v"(a), "v"(pb[2 * kb + st])); }
+                    else o[db] = M::run(a, pb[2 * kb + st], o[db]);
+                }
+            }
+    };
+    // M(t) as one software-pipelined stream of 2*KS + 4*DB MFMAs: the LDS fragment of MFMA
+    // i + FW is requested when MFMA i issues, so FW fragment reads are always in flight
+    // (an LDS read issued right before its MFMA costs the whole LDS latency per MFMA).
+    constexpr int NQ = 2 * KS, NP = 4 * DB, FW = 8;
+    auto m_phase = [&](int kslot, int vslot) {
+        const char* Kb = lds + kslot * TILE_B;
+        const char* Vb = lds + (2 + vslot) * TILE_B;
+        auto frag = [&](int i) -> s16x8 {
+            if (i < NQ) {
+                const int kb = i / KS, ks = i % KS;
+                return *reinterpret_cast<const s16x8*>(Kb + k_off<D>(32 * kb + r, 2 * ks + h));
+            }
+            const int j = i - NQ, kb = j / (2 * DB), st = (j / DB) & 1, db = j % DB;
+            const int r0 = 32 * kb + 16 * st + 4 * h + tq;
+            const int ch = 4 * db + 2 * tg1 + (tp >> 1);
+            const s16x4 lo = lds_read_tr(Vb + v_off<D>(r0, ch) + 8 * (tp & 1));
+            const s16x4 hi = lds_read_tr(Vb + v_off<D>(r0 + 8, ch) + 8 * (tp & 1));
+            s16x8 a;
+            a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
+            a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
+            return a;
+        };
+        s16x8 win[FW];
+#pragma unroll
+        for (int i = 0; i < FW; ++i) win[i] = frag(i);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NQ + NP; ++i) {
+            const s16x8 a = win[i % FW];
+            if (i < NQ) {
+                s[i / KS] = M::run(a, qf[i % KS], s[i / KS]);
+            } else {
+                const int j = i - NQ;
+                o[j % DB] = M::run(a, pb[j / DB], o[j % DB]);
+            }
+            if (i + FW < NQ + NP) win[i % FW] = frag(i + FW);
+        }
+    };
+    unsigned long long cyc_x1 = 0, cyc_x2 = 0;
+    auto softmax = [&](int kv0) {
+        unsigned long long s0 = 0, s1 = 0, s2 = 0;
+        if constexpr (ABLATE & 2) {   // timing-only build: no softmax arithmetic
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pb[2 * kb + st][j] = (T)s[kb][8 * st + j];
+            l += 1.0f;
+            return;
+        }
+        if constexpr (STAMP) s0 = stamp();
+        if (kv0 + kBKV > N) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kv0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= N) s[kb][i] = -INFINITY;
+                }
+        }
+        // four independent max chains (a single chain of 32 dependent ops issues at VALU latency)
+        float mx[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mx[c] = fmaxf(s[c >> 1][8 * (c & 1)], s[c >> 1][8 * (c & 1) + 1]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 2; i < 8; i += 2)
+                mx[c] = fmaxf(fmaxf(mx[c], s[c >> 1][8 * (c & 1) + i]), s[c >> 1][8 * (c & 1) + i + 1]);
+        const float tmax = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+        const float mt = half_exchange_max(tmax) * sl2;
+        if constexpr (STAMP) s1 = stamp();
+        if (__builtin_amdgcn_ballot_w64(mt - m > thr) != 0) {   // wave-uniform
+            const float m_new = fmaxf(m, mt);
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            m = m_new;
+            l *= alpha;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+        }
+        if constexpr (STAMP) { s2 = stamp(); cyc_x2 += s2 - s1; }
+        // separate passes, so that no instruction waits on the one just before it
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[kb][i] = __builtin_fmaf(s[kb][i], sl2, -m);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[kb][i] = __builtin_amdgcn_exp2f(s[kb][i]);
+        __builtin_amdgcn_sched_barrier(0);
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ps[i & 3] += s[kb][i];
+        l += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[2 * kb + st][j] = (T)s[kb][8 * st + j];
+    };
+
+    const int T_ = (N + kBKV - 1) / kBKV;
+
+    // ---- prologue: K(0), V(0), K(1) into LDS.  Every load and LDS write below is
+    // unconditional (tiles past the end re-read the last rows into a slot nobody reads
+    // again): a load under a condition makes hipcc protect the staging registers with
+    // s_waitcnt vmcnt(0), which serialises each tile's K and V loads behind each other.
+    load_tile(kst, Kh, 0);
+    load_tile(vst, Vh, 0);
+    write_k(0);
+    write_v(0);
+    load_tile(kst, Kh, 1);
+    write_k(1);
+    __syncthreads();
+
+    qk(0);
+    if (grp) __syncthreads();
+    load_tile(kst, Kh, 2);
+    load_tile(vst, Vh, 1);
+    softmax(0);
+    __syncthreads();
+
+    unsigned long long cyc_m = 0, cyc_mw = 0, cyc_x = 0, cyc_xw = 0, cyc_mm = 0;
+    for (int t = 0; t + 1 < T_; ++t) {
+        unsigned long long ta = 0, tb = 0, tc = 0, td = 0, te = 0, tmm = 0;
+        if constexpr (STAMP) ta = stamp();
+        // ---- M(t)
+        m_phase((t + 1) & 1, t & 1);
+        if constexpr (STAMP) tmm = stamp();
+        write_k(t & 1);            // K(t+2)
+        write_v((t + 1) & 1);      // V(t+1)
+        if constexpr (STAMP) tb = stamp();
+        __syncthreads();
+        if constexpr (STAMP) tc = stamp();
+        // ---- X(t+1)
+        load_tile(kst, Kh, t + 3);
+        load_tile(vst, Vh, t + 2);
+        if constexpr (STAMP) { const unsigned long long tl = stamp(); cyc_x1 += tl - tc; }
+        softmax((t + 1) * kBKV);
+        if constexpr (STAMP) td = stamp();
+        __syncthreads();
+        if constexpr (STAMP) {
+            te = stamp();
+            cyc_mm += tmm - ta; cyc_m += tb - ta; cyc_mw += tc - tb;
+            cyc_x += td - tc; cyc_xw += te - td;
+        }
+    }
+    pv((T_ - 1) & 1);              // M(T-1): nothing left to prefetch
+    if (grp == 0) __syncthreads(); // the leading half meets the lagging half's last barrier
+    if constexpr (STAMP) {
+        if (dbg != nullptr && (wave == 0 || wave == 4) && lane == 0) {
+            unsigned long long* d = dbg + (size_t)blockIdx.x * 14 + (wave >> 2) * 7;
+            d[0] = cyc_m; d[1] = cyc_mw; d[2] = cyc_x; d[3] = cyc_xw; d[4] = cyc_mm; d[5] = cyc_x1; d[6] = cyc_x2;
+        }
+    }
+
+    const float ltot = half_exchange_sum(l);
+    const float inv = 1.0f / ltot;
+    if (qrow < N) {
+        T* orow = Og + hoff + (size_t)qrow * D;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                vec4 w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = (T)(o[db][4 * g + j] * inv);
+                *reinterpret_cast<vec4*>(orow + 32 * db + 8 * g + 4 * h) = w;
+            }
+        if (LSEg != nullptr && h == 0)
+            LSEg[(size_t)head * N + qrow] = (m + __builtin_amdgcn_logf(ltot)) * 0.6931471805599453f;
+    }
+}
+
+// Benchmark-only knobs, read at every launch so one process can A/B them:
+// MYFA_ATTN_VARIANT (0 = one-barrier loop, 1 = ping-pong, the default) and
+// MYFA_ATTN_THR (deferred-max threshold in log2 units, default 0 = exact).
+struct Tuning { int variant; float thr; unsigned long long* dbg; int ablate; };
+Tuning tuning() {
+    Tuning x{1, 0.f, nullptr, 0};
+    if (const char* e = std::getenv("MYFA_ATTN_ABLATE")) x.ablate = std::atoi(e);   // stamped builds only
+    // MYFA_ATTN_DBG = device address (decimal) of a 14 * nwg u64 buffer: selects the stamped build
+    if (const char* e = std::getenv("MYFA_ATTN_DBG")) x.dbg = reinterpret_cast<unsigned long long*>(std::strtoull(e, nullptr, 10));
+    if (const char* e = std::getenv("MYFA_ATTN_VARIANT")) x.variant = std::atoi(e);
+    if (const char* e = std::getenv("MYFA_ATTN_THR")) x.thr = (float)std::atof(e);
+    return x;
+}
+
 template <typename T, int D>
 int launch(const void* q, const void* k, const void* v, void* o, float* lse,
            int64_t heads, int64_t N, float scale, hipStream_t s) {
@@ -295,9 +646,28 @@ int launch(const void* q, const void* k, const void* v, void* o, float* lse,
     const int64_t nwg = heads * nqblk;
     if (nwg > 0x7fffffffLL) return fail(MYFA_E_UNSUPPORTED, "attention: too many workgroups (%lld)", (long long)nwg);
     const float sl2 = scale * 1.4426950408889634f;
-    hipLaunchKernelGGL((attn_fwd_mfma_kernel<T, D>), dim3((unsigned)nwg), dim3(kThreads), 0, s,
-                       static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
-                       static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2);
+    const Tuning tn = tuning();
+    if (tn.variant == 0)
+        hipLaunchKernelGGL((attn_fwd_mfma_kernel<T, D>), dim3((unsigned)nwg), dim3(kThreads), 0, s,
+                           static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
+                           static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2);
+    else if (tn.dbg != nullptr && tn.ablate == 1)
+        hipLaunchKernelGGL((attn_fwd_mfma_pp_kernel<T, D, true, 1>), dim3((unsigned)nwg), dim3(kThreads), 0, s,
+                           static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
+                           static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, tn.thr, tn.dbg);
+    else if (tn.dbg != nullptr && tn.ablate == 2)
+        hipLaunchKernelGGL((attn_fwd_mfma_pp_kernel<T, D, true, 2>), dim3((unsigned)nwg), dim3(kThreads), 0, s,
+                           static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
+                           static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, tn.thr, tn.dbg);
+    else if (tn.dbg != nullptr)
+        hipLaunchKernelGGL((attn_fwd_mfma_pp_kernel<T, D, true>), dim3((unsigned)nwg), dim3(kThreads), 0, s,
+                           static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
+                           static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, tn.thr, tn.dbg);
+    else
+        hipLaunchKernelGGL((attn_fwd_mfma_pp_kernel<T, D, false>), dim3((unsigned)nwg), dim3(kThreads), 0, s,
+                           static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
+                           static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, tn.thr,
+                           (unsigned long long*)nullptr);
     return check_launch("attn_fwd_mfma");
 }
 

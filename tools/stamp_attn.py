@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares of the ping-pong attention kernel (stamped build)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "flash-attention_amd"))
+import torch
+import my_flash_attn_cuda as mfa
+B, H, N, d = 4, 32, 4096, 128
+torch.manual_seed(1)
+q, k, v = (torch.randn(B, H, N, d, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+nwg = B * H * (N // 256)
+dbg = torch.zeros(nwg * 14, dtype=torch.int64, device="cuda")
+for key, val in [kv.split("=") for kv in sys.argv[1:]]:
+    os.environ["MYFA_ATTN_" + key] = val
+os.environ["MYFA_ATTN_DBG"] = str(dbg.data_ptr())
+for _ in range(3):
+    mfa.flash_attn_fwd(q, k, v, scale=d ** -0.5)
+torch.cuda.synchronize()
+x = dbg.view(nwg, 2, 7).double().cpu()
+T = N // 64
+names = ["M body", "M barrier wait", "X body", "X barrier wait", "M mfma part", "X load issue", "X rescale part"]
+for g in range(2):
+    print(f"wave {4*g}: " + "  ".join(f"{n}: {x[:, g, i].median().item() / T:8.1f}" for i, n in enumerate(names)) + "  (cycles per tile, median over WGs)")
