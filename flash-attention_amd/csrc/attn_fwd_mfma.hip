@@ -64,6 +64,7 @@ template <> struct Mma<_Float16> {
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ s16x4 lds_read_tr(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
@@ -294,29 +295,41 @@ attn_fwd_mfma_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T
 
 
 // ---------------------------------------------------------------------------
-// Ping-pong variant.  Same tiles, LDS images and register choreography as the
-// kernel above, different schedule: the loop is software-pipelined into a
-// matrix phase  M(t) = { S(t+1) = K(t+1) Q^T ;  O += V(t)^T P(t)^T }  (32 MFMAs
-// back to back) and a vector phase  X(t+1) = { online softmax of S(t+1) -> P(t+1),
-// rescale O }, and the two waves that share a SIMD (wave w and wave w+4) run in
-// opposite phases, one barrier per phase: while waves 0-3 keep the matrix pipe
-// busy, waves 4-7 do their exponentials on the vector pipe, and vice versa.
-// Waves 4-7 simply run the same program one phase late.
+// Ping-pong variant (the default).  Same tiles and register choreography as the
+// kernel above; different schedule and a different LDS image.
 //
-// LDS hand-over with two K slots and two V slots: M(u) reads K(u+1), V(u) and
-// -- after its MFMAs -- publishes this thread's share of K(u+2) (into the slot
-// K(u) has left) and V(u+1); the global loads for those were issued one phase
-// earlier, in X(u).  Waves 0-3 run M(u) in phase 2u and waves 4-7 in phase 2u+1;
-// the readers of K(u+2)/V(u+1) are M(u+1) in phases 2u+2 / 2u+3, behind the
-// barrier that ends phase 2u+1; the data they replace was last read by M(u-1)
-// in phases 2u-2 / 2u-1.
+// Schedule.  The loop is software-pipelined into a matrix phase
+//   M(t) = { S(t+1) = K(t+1) Q^T ;  O += V(t)^T P(t)^T }      (32 MFMAs back to back)
+// and a vector phase
+//   X(t+1) = { online softmax of S(t+1) -> P(t+1), rescale O },
+// and the two waves that share a SIMD (wave w and wave w+4) run in opposite
+// phases, one barrier per phase: while waves 0-3 keep the matrix pipe busy,
+// waves 4-7 do their exponentials on the vector pipe, and vice versa.  Waves 4-7
+// simply run the same program one phase late.
+//
+
+//
+// Instruction economy.  Both waves of a SIMD issue their vector AND matrix
+// instructions through the same port, so every address computation in the loop
+// is paid for twice.  Hence:
+//  * one LDS image for K and V tiles, made of 8-row x 64-byte subtiles,
+//        off(row, c) = 16*D*(row>>3) + 512*(c>>2) + 64*(row&7) + 16*((c&3) ^ ((row>>2)&3))
+//    (c = 16-byte chunk of the row).  Both the row reads of K (ds_read_b128) and the
+//    transposing reads of V (ds_read_b64_tr_b16) are bank-conflict-free on it, and
+//    every fragment address is one of four per-lane bases plus a compile-time
+//    immediate, so the matrix phase computes no addresses at all (the loop is
+//    unrolled by two to make the slot a compile-time constant);
+//  * K/V tiles are fetched with LDS-DMA buffer loads: per-lane source offset fixed, tile
+//    offset in a scalar register, rows past N return zero (no clamping arithmetic, no
+//    staging registers, no ds_write pass).
 //
 // `thr` is the deferred-max threshold in log2 units: the running max only moves
 // (and O, l are only rescaled) in a tile where some row's max grew by more than
 // thr.  thr = 0 rescales whenever any max grew, which is exactly the textbook
 // recurrence; thr > 0 lets P reach 2^thr.
+
 // STAMP builds are diagnostic only: they bracket the phases with s_memtime and write the
-// per-phase cycle sums of waves 0 and 4 to `dbg` (8 u64 per workgroup); never timed.
+// per-phase cycle sums of waves 0 and 4 to `dbg` (14 u64 per workgroup); never timed.
 __device__ __forceinline__ unsigned long long stamp() {
     __builtin_amdgcn_sched_barrier(0);
     unsigned long long t;
@@ -325,7 +338,13 @@ __device__ __forceinline__ unsigned long long stamp() {
     return t;
 }
 
-template <typename T, int D, bool STAMP = false, int ABLATE = 0>
+template <int V> struct IC { static constexpr int value = V; };
+
+template <int D> __device__ __forceinline__ constexpr int img_off(int row, int ch) {
+    return 16 * D * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+}
+
+template <typename T, int D, bool STAMP = false>
 __global__ void __launch_bounds__(kThreads, 2)
 attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* __restrict__ Vg,
                         T* __restrict__ Og, float* __restrict__ LSEg, int N, int nqblk, int nwg,
@@ -335,12 +354,13 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
     using vec4 = typename M::vec4;
     constexpr int CPR = D / 8;
     constexpr int TILE_B = kBKV * D * 2;
+    constexpr int SUB_B = 16 * D;                // bytes of one 8-row group of the image
     constexpr int KS = D / 16;
     constexpr int DB = D / 32;
     constexpr int LPT = kBKV * CPR / kThreads;
     static_assert(LPT >= 1, "tile smaller than one load per thread");
 
-    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_B];   // K0 K1 V0 V1
+    __shared__ __attribute__((aligned(16))) char lds[6 * TILE_B];   // K ring of 3, V ring of 3
 
     int lid;
     {
@@ -358,8 +378,6 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
 
     const size_t hoff = (size_t)head * (size_t)N * D;
     const T* Qh = Qg + hoff;
-    const T* Kh = Kg + hoff;
-    const T* Vh = Vg + hoff;
 
     const int qrow = q0 + wave * 32 + r;
     const int qrow_c = qrow < N ? qrow : N - 1;
@@ -368,32 +386,49 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
     for (int ks = 0; ks < KS; ++ks)
         qf[ks] = *reinterpret_cast<const vec8*>(Qh + (size_t)qrow_c * D + 16 * ks + 8 * h);
 
-    // ---- register staging, K and V separately
-    u32x4 kst[LPT], vst[LPT];
-    auto load_tile = [&](u32x4 (&st)[LPT], const T* base, int tile) {
+    // ---- K/V tiles go HBM/L2 -> LDS directly (buffer_load ... lds): no staging registers, no
+    // ds_write pass.  One wave-instruction fills 1 KiB of LDS, lane L at base + 16 L, so the
+    // image is produced by choosing each lane's SOURCE chunk: piece `pc` of a tile covers
+    // image bytes [1024 pc, 1024 pc + 1024); lane L owns 16-byte unit u = 64 pc + L, which by
+    // the image formula is (row, chunk) below.  Rows past N read as zero (buffer bounds).
+    const unsigned head_bytes = (unsigned)N * D * 2;
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)(Kg + hoff), 0, head_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(Vg + hoff), 0, head_bytes, 0x00020000);
+    [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int st_goff[LPT];
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const int id = tid + kThreads * i;
-            const int row = id / CPR, ch = id % CPR;
-            int g = tile * kBKV + row;
-            g = g < N ? g : N - 1;            // past the end: any valid row (masked or never used)
-            st[i] = *reinterpret_cast<const u32x4*>(base + (size_t)g * D + ch * 8);
-        }
-    };
-    auto write_k = [&](int slot) {
+    for (int i = 0; i < LPT; ++i) {
+        const int u = 64 * (wave * LPT + i) + lane;
+        const int grp8 = u / (SUB_B / 16), within = u % (SUB_B / 16);
+        const int row = 8 * grp8 + ((within & 31) >> 2);
+        const int ch = 4 * (within >> 5) + ((within & 3) ^ ((row >> 2) & 3));
+        st_goff[i] = (row * D + ch * 8) * 2;
+    }
+    // (The host pass of hipcc silently drops a kernel whose body names this builtin, and the
+    // launch stub with it; the body only exists in the device pass.)
+    auto fetch = [&](const __amdgpu_buffer_rsrc_t& rs, int tile, int lds_byte) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const int id = tid + kThreads * i;
-            *reinterpret_cast<u32x4*>(lds + slot * TILE_B + k_off<D>(id / CPR, id % CPR)) = kst[i];
-        }
+        for (int i = 0; i < LPT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + lds_byte + 1024 * (wave_u * LPT + i)),
+                                                     16, st_goff[i], tile * TILE_B, 0, 0);
+#endif
     };
-    auto write_v = [&](int slot) {
+    auto fetch_k = [&](int tile, int slot) __attribute__((always_inline)) { fetch(krs, tile, slot * TILE_B); };
+    auto fetch_v = [&](int tile, int slot) __attribute__((always_inline)) { fetch(vrs, tile, (3 + slot) * TILE_B); };
+
+    // ---- per-lane bases of the fragment reads (everything else is an immediate)
+    // K row read, key block kb, k-step ks: row = 32kb + r, chunk = 2ks + h
+    int kbase[2];
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const int id = tid + kThreads * i;
-            *reinterpret_cast<u32x4*>(lds + (2 + slot) * TILE_B + v_off<D>(id / CPR, id % CPR)) = vst[i];
-        }
-    };
+    for (int e = 0; e < 2; ++e)
+        kbase[e] = SUB_B * (r >> 3) + 64 * (r & 7) + 16 * ((2 * e + h) ^ ((r >> 2) & 3));
+    // V transposing read: row = 32kb + 16st + 8hi + 4h + tq, chunk = 4db + 2tg1 + (tp>>1), half tp&1
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
+    int vbase[2];
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi)
+        vbase[hi] = 64 * (4 * h + tq) + 16 * ((2 * tg1 + (tp >> 1)) ^ (2 * hi + h)) + 8 * (tp & 1);
 
     f32x16 o[DB];
 #pragma unroll
@@ -404,97 +439,55 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
     f32x16 s[2];
     vec8 pb[4];
 
-    const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
-
-    auto qk = [&](int slot) {
-        const char* Kb = lds + slot * TILE_B;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const s16x8 a = *reinterpret_cast<const s16x8*>(Kb + k_off<D>(32 * kb + r, 2 * ks + h));
-                if constexpr (ABLATE & 1) { asm volatile("" :: "v"(a)); s[kb][ks] += 1.0f; }
-                else s[kb] = M::run(a, qf[ks], s[kb]);
-            }
-        }
-    };
-    auto pv = [&](int slot) {
-        const char* Vb = lds + (2 + slot) * TILE_B;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                const int r0 = 32 * kb + 16 * st + 4 * h + tq;
-#pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const int ch = 4 * db + 2 * tg1 + (tp >> 1);
-                    const s16x4 lo = lds_read_tr(Vb + v_off<D>(r0, ch) + 8 * (tp & 1));
-                    const s16x4 hi = lds_read_tr(Vb + v_off<D>(r0 + 8, ch) + 8 * (tp & 1));
-                    s16x8 a;
-                    a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
-                    a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
-                    if constexpr (ABLATE & 1) { asm volatile("" :: "v"(a), "v"(pb[2 * kb + st])); }
-                    else o[db] = M::run(a, pb[2 * kb + st], o[db]);
-                }
-            }
-    };
-    // M(t) as one software-pipelined stream of 2*KS + 4*DB MFMAs: the LDS fragment of MFMA
-    // i + FW is requested when MFMA i issues, so FW fragment reads are always in flight
-    // (an LDS read issued right before its MFMA costs the whole LDS latency per MFMA).
     constexpr int NQ = 2 * KS, NP = 4 * DB, FW = 8;
-    auto m_phase = [&](int kslot, int vslot) {
-        const char* Kb = lds + kslot * TILE_B;
-        const char* Vb = lds + (2 + vslot) * TILE_B;
-        auto frag = [&](int i) -> s16x8 {
-            if (i < NQ) {
-                const int kb = i / KS, ks = i % KS;
-                return *reinterpret_cast<const s16x8*>(Kb + k_off<D>(32 * kb + r, 2 * ks + h));
-            }
-            const int j = i - NQ, kb = j / (2 * DB), st = (j / DB) & 1, db = j % DB;
-            const int r0 = 32 * kb + 16 * st + 4 * h + tq;
-            const int ch = 4 * db + 2 * tg1 + (tp >> 1);
-            const s16x4 lo = lds_read_tr(Vb + v_off<D>(r0, ch) + 8 * (tp & 1));
-            const s16x4 hi = lds_read_tr(Vb + v_off<D>(r0 + 8, ch) + 8 * (tp & 1));
-            s16x8 a;
-            a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
-            a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
-            return a;
-        };
+    // fragment i of the matrix phase: i < NQ: K fragment (kb = i / KS, ks = i % KS) of K slot
+    // KSLOT; otherwise V fragment (kb, st, db) of V slot VSLOT.  `i` is a constant after
+    // unrolling, so each address is a per-lane base plus an immediate.
+    auto frag = [&](int kbyte, int vbyte, int i) __attribute__((always_inline)) -> s16x8 {
+        if (i < NQ) {
+            const int kb = i / KS, ks = i % KS;
+            const int imm = SUB_B * 4 * kb + 512 * (ks >> 1);
+            return *reinterpret_cast<const s16x8*>(lds + (kbase[ks & 1] + kbyte) + imm);
+        }
+        const int j = i - NQ, kb = j / (2 * DB), st = (j / DB) & 1, db = j % DB;
+        const int imm = SUB_B * (4 * kb + 2 * st) + 512 * db;
+        const s16x4 lo = lds_read_tr(lds + (vbase[0] + vbyte) + imm);
+        const s16x4 hi = lds_read_tr(lds + (vbase[1] + vbyte) + imm + SUB_B);
+        s16x8 a;
+        a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
+        a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
+        return a;
+    };
+    // The matrix phase as one software-pipelined stream: the fragment of MFMA i + FW is
+    // requested when MFMA i issues.  [FIRST, LAST) selects QK only, PV only, or both.
+    // kslot / vslot: ring slots (wave-uniform) of the K and V tiles read.
+    auto mma_stream = [&](int kslot, int vslot, auto first_, auto last_) __attribute__((always_inline)) {
+        constexpr int FIRST = decltype(first_)::value, LAST = decltype(last_)::value;
+        const int kbyte = kslot * TILE_B, vbyte = (3 + vslot) * TILE_B;
         s16x8 win[FW];
 #pragma unroll
-        for (int i = 0; i < FW; ++i) win[i] = frag(i);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
-#pragma unroll
-        for (int i = 0; i < NQ + NP; ++i) {
-            const s16x8 a = win[i % FW];
-            if (i < NQ) {
-                s[i / KS] = M::run(a, qf[i % KS], s[i / KS]);
-            } else {
-                const int j = i - NQ;
-                o[j % DB] = M::run(a, pb[j / DB], o[j % DB]);
-            }
-            if (i + FW < NQ + NP) win[i % FW] = frag(i + FW);
-        }
-    };
-    unsigned long long cyc_x1 = 0, cyc_x2 = 0;
-    auto softmax = [&](int kv0) {
-        unsigned long long s0 = 0, s1 = 0, s2 = 0;
-        if constexpr (ABLATE & 2) {   // timing-only build: no softmax arithmetic
+        for (int i = FIRST; i < FIRST + FW; ++i)
+            if (i < LAST) win[(i - FIRST) % FW] = frag(kbyte, vbyte, i);
+        if constexpr (FIRST < NQ) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int st = 0; st < 2; ++st)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pb[2 * kb + st][j] = (T)s[kb][8 * st + j];
-            l += 1.0f;
-            return;
+                for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
         }
-        if constexpr (STAMP) s0 = stamp();
+#pragma unroll
+        for (int i = FIRST; i < LAST; ++i) {
+            const s16x8 a = win[(i - FIRST) % FW];
+            if (i < NQ) s[i / KS] = M::run(a, qf[i % KS], s[i / KS]);
+            else o[(i - NQ) % DB] = M::run(a, pb[(i - NQ) / DB], o[(i - NQ) % DB]);
+            if (i + FW < LAST) win[(i - FIRST) % FW] = frag(kbyte, vbyte, i + FW);
+            // pin the order: left alone, the scheduler sinks every read to just before its MFMA
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    unsigned long long cyc_x1 = 0, cyc_x2 = 0;
+    auto softmax = [&](int kv0) __attribute__((always_inline)) {
+        unsigned long long s1 = 0, s2 = 0;
         if (kv0 + kBKV > N) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -504,16 +497,11 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
                     if (key >= N) s[kb][i] = -INFINITY;
                 }
         }
-        // four independent max chains (a single chain of 32 dependent ops issues at VALU latency)
-        float mx[4];
+        float tmax = s[0][0];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) mx[c] = fmaxf(s[c >> 1][8 * (c & 1)], s[c >> 1][8 * (c & 1) + 1]);
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int i = 2; i < 8; i += 2)
-                mx[c] = fmaxf(fmaxf(mx[c], s[c >> 1][8 * (c & 1) + i]), s[c >> 1][8 * (c & 1) + i + 1]);
-        const float tmax = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+            for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, s[kb][i]);
         const float mt = half_exchange_max(tmax) * sl2;
         if constexpr (STAMP) s1 = stamp();
         if (__builtin_amdgcn_ballot_w64(mt - m > thr) != 0) {   // wave-uniform
@@ -527,23 +515,15 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
                 for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
         }
         if constexpr (STAMP) { s2 = stamp(); cyc_x2 += s2 - s1; }
-        // separate passes, so that no instruction waits on the one just before it
+        float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s[kb][i] = __builtin_fmaf(s[kb][i], sl2, -m);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s[kb][i] = __builtin_amdgcn_exp2f(s[kb][i]);
-        __builtin_amdgcn_sched_barrier(0);
-        float ps[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) ps[i & 3] += s[kb][i];
-        l += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+            for (int i = 0; i < 16; ++i) {
+                s[kb][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], sl2, -m));
+                psum += s[kb][i];
+            }
+        l += psum;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -554,52 +534,61 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
 
     const int T_ = (N + kBKV - 1) / kBKV;
 
-    // ---- prologue: K(0), V(0), K(1) into LDS.  Every load and LDS write below is
-    // unconditional (tiles past the end re-read the last rows into a slot nobody reads
-    // again): a load under a condition makes hipcc protect the staging registers with
-    // s_waitcnt vmcnt(0), which serialises each tile's K and V loads behind each other.
-    load_tile(kst, Kh, 0);
-    load_tile(vst, Vh, 0);
-    write_k(0);
-    write_v(0);
-    load_tile(kst, Kh, 1);
-    write_k(1);
+    // Own LDS-DMA fetches have landed / phase boundary without draining the ones in flight.
+    auto dma_wait = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    auto phase_barrier = [&]() __attribute__((always_inline)) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // ---- prologue: K(0), V(0), K(1) into LDS.  Every fetch in this kernel is unconditional
+    // (tiles past the end read zeros into a slot nobody reads again).
+    fetch_k(0, 0);
+    fetch_v(0, 0);
+    fetch_k(1, 1);
+    dma_wait();
     __syncthreads();
 
-    qk(0);
+    mma_stream(0, 0, IC<0>{}, IC<NQ>{});     // S(0) = K(0) Q^T
     if (grp) __syncthreads();
-    load_tile(kst, Kh, 2);
-    load_tile(vst, Vh, 1);
+    fetch_k(2, 2);
+    fetch_v(1, 1);
     softmax(0);
-    __syncthreads();
+    phase_barrier();
 
     unsigned long long cyc_m = 0, cyc_mw = 0, cyc_x = 0, cyc_xw = 0, cyc_mm = 0;
+    int s0 = 0, s1 = 1, s2 = 2;      // t % 3, (t+1) % 3, (t+2) % 3
     for (int t = 0; t + 1 < T_; ++t) {
-        unsigned long long ta = 0, tb = 0, tc = 0, td = 0, te = 0, tmm = 0;
+        unsigned long long ta = 0, tb = 0, tc = 0, td = 0, te = 0;
         if constexpr (STAMP) ta = stamp();
-        // ---- M(t)
-        m_phase((t + 1) & 1, t & 1);
-        if constexpr (STAMP) tmm = stamp();
-        write_k(t & 1);            // K(t+2)
-        write_v((t + 1) & 1);      // V(t+1)
+        // ---- M(t): reads K(t+1), V(t).  This wave's fetches of them were issued two
+        // vector phases ago; make sure they have landed before the barrier that ends M(t),
+        // which is what tells the other waves that this wave's share is in place.
+        dma_wait();
+        mma_stream(s1, s0, IC<0>{}, IC<NQ + NP>{});
         if constexpr (STAMP) tb = stamp();
         __syncthreads();
         if constexpr (STAMP) tc = stamp();
-        // ---- X(t+1)
-        load_tile(kst, Kh, t + 3);
-        load_tile(vst, Vh, t + 2);
-        if constexpr (STAMP) { const unsigned long long tl = stamp(); cyc_x1 += tl - tc; }
+        // ---- X(t+1): fetch K(t+3) into the slot K(t) has left (last read in M(t-1)) and
+        // V(t+2) into the slot V(t-1) has left; they are first read in M(t+2) / M(t+1),
+        // at least two barriers from now, and the barrier below must not wait for them.
+        fetch_k(t + 3, s0);
+        fetch_v(t + 2, s2);
         softmax((t + 1) * kBKV);
         if constexpr (STAMP) td = stamp();
-        __syncthreads();
+        phase_barrier();
         if constexpr (STAMP) {
             te = stamp();
-            cyc_mm += tmm - ta; cyc_m += tb - ta; cyc_mw += tc - tb;
+            cyc_mm += tb - ta; cyc_m += tb - ta; cyc_mw += tc - tb;
             cyc_x += td - tc; cyc_xw += te - td;
         }
+        const int n = s0; s0 = s1; s1 = s2; s2 = n;
     }
-    pv((T_ - 1) & 1);              // M(T-1): nothing left to prefetch
-    if (grp == 0) __syncthreads(); // the leading half meets the lagging half's last barrier
+    dma_wait();
+    mma_stream(0, s0, IC<NQ>{}, IC<NQ + NP>{});   // M(T-1): O += V(T-1)^T P^T
+    if (grp == 0) __syncthreads();   // the leading half meets the lagging half's last barrier
+
     if constexpr (STAMP) {
         if (dbg != nullptr && (wave == 0 || wave == 4) && lane == 0) {
             unsigned long long* d = dbg + (size_t)blockIdx.x * 14 + (wave >> 2) * 7;
@@ -628,10 +617,9 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
 // Benchmark-only knobs, read at every launch so one process can A/B them:
 // MYFA_ATTN_VARIANT (0 = one-barrier loop, 1 = ping-pong, the default) and
 // MYFA_ATTN_THR (deferred-max threshold in log2 units, default 0 = exact).
-struct Tuning { int variant; float thr; unsigned long long* dbg; int ablate; };
+struct Tuning { int variant; float thr; unsigned long long* dbg; };
 Tuning tuning() {
-    Tuning x{1, 0.f, nullptr, 0};
-    if (const char* e = std::getenv("MYFA_ATTN_ABLATE")) x.ablate = std::atoi(e);   // stamped builds only
+    Tuning x{1, 0.f, nullptr};
     // MYFA_ATTN_DBG = device address (decimal) of a 14 * nwg u64 buffer: selects the stamped build
     if (const char* e = std::getenv("MYFA_ATTN_DBG")) x.dbg = reinterpret_cast<unsigned long long*>(std::strtoull(e, nullptr, 10));
     if (const char* e = std::getenv("MYFA_ATTN_VARIANT")) x.variant = std::atoi(e);
@@ -651,14 +639,6 @@ int launch(const void* q, const void* k, const void* v, void* o, float* lse,
         hipLaunchKernelGGL((attn_fwd_mfma_kernel<T, D>), dim3((unsigned)nwg), dim3(kThreads), 0, s,
                            static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
                            static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2);
-    else if (tn.dbg != nullptr && tn.ablate == 1)
-        hipLaunchKernelGGL((attn_fwd_mfma_pp_kernel<T, D, true, 1>), dim3((unsigned)nwg), dim3(kThreads), 0, s,
-                           static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
-                           static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, tn.thr, tn.dbg);
-    else if (tn.dbg != nullptr && tn.ablate == 2)
-        hipLaunchKernelGGL((attn_fwd_mfma_pp_kernel<T, D, true, 2>), dim3((unsigned)nwg), dim3(kThreads), 0, s,
-                           static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
-                           static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, tn.thr, tn.dbg);
     else if (tn.dbg != nullptr)
         hipLaunchKernelGGL((attn_fwd_mfma_pp_kernel<T, D, true>), dim3((unsigned)nwg), dim3(kThreads), 0, s,
                            static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
