@@ -196,7 +196,7 @@ def main():
                    "B": B, "H": H, "N": N, "d": d, "sharding": f"batch x heads, {world} rank(s), no collective"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                     "kernel": "attn_fwd_mfma_kernel", "launch_ms_mean": round(mean_ms, 4),
+                     "kernel": "attn_fwd_mfma_pp_kernel", "launch_ms_mean": round(mean_ms, 4),
                      "launch_ms_median": round(med_ms, 4), "flops_per_launch": flops},
     }
     if rank == 0 and world == 1 and not args.no_extras:

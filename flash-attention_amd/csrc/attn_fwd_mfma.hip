@@ -344,7 +344,7 @@ template <int D> __device__ __forceinline__ constexpr int img_off(int row, int c
     return 16 * D * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
 }
 
-template <typename T, int D, bool STAMP = false>
+template <typename T, int D, bool STAMP = false, int OPT = 0>
 __global__ void __launch_bounds__(kThreads, 2)
 attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* __restrict__ Vg,
                         T* __restrict__ Og, float* __restrict__ LSEg, int N, int nqblk, int nwg,
@@ -566,7 +566,10 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
         // vector phases ago; make sure they have landed before the barrier that ends M(t),
         // which is what tells the other waves that this wave's share is in place.
         dma_wait();
+        // the matrix stream outranks the partner wave's vector work for the shared issue port
+        if constexpr (OPT & 1) __builtin_amdgcn_s_setprio(1);
         mma_stream(s1, s0, IC<0>{}, IC<NQ + NP>{});
+        if constexpr (OPT & 1) __builtin_amdgcn_s_setprio(0);
         if constexpr (STAMP) tb = stamp();
         __syncthreads();
         if constexpr (STAMP) tc = stamp();
@@ -616,10 +619,11 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
 
 // Benchmark-only knobs, read at every launch so one process can A/B them:
 // MYFA_ATTN_VARIANT (0 = one-barrier loop, 1 = ping-pong, the default) and
-// MYFA_ATTN_THR (deferred-max threshold in log2 units, default 0 = exact).
-struct Tuning { int variant; float thr; unsigned long long* dbg; };
+// MYFA_ATTN_THR (deferred-max threshold in log2 units, default 8; 0 = rescale whenever a max grows).
+struct Tuning { int variant; float thr; unsigned long long* dbg; int opt; };
 Tuning tuning() {
-    Tuning x{1, 0.f, nullptr};
+    Tuning x{1, 8.f, nullptr, 0};
+    if (const char* e = std::getenv("MYFA_ATTN_OPT")) x.opt = std::atoi(e);   // experimental build variants
     // MYFA_ATTN_DBG = device address (decimal) of a 14 * nwg u64 buffer: selects the stamped build
     if (const char* e = std::getenv("MYFA_ATTN_DBG")) x.dbg = reinterpret_cast<unsigned long long*>(std::strtoull(e, nullptr, 10));
     if (const char* e = std::getenv("MYFA_ATTN_VARIANT")) x.variant = std::atoi(e);
@@ -639,15 +643,16 @@ int launch(const void* q, const void* k, const void* v, void* o, float* lse,
         hipLaunchKernelGGL((attn_fwd_mfma_kernel<T, D>), dim3((unsigned)nwg), dim3(kThreads), 0, s,
                            static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
                            static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2);
-    else if (tn.dbg != nullptr)
-        hipLaunchKernelGGL((attn_fwd_mfma_pp_kernel<T, D, true>), dim3((unsigned)nwg), dim3(kThreads), 0, s,
-                           static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
-                           static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, tn.thr, tn.dbg);
-    else
-        hipLaunchKernelGGL((attn_fwd_mfma_pp_kernel<T, D, false>), dim3((unsigned)nwg), dim3(kThreads), 0, s,
-                           static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
-                           static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, tn.thr,
-                           (unsigned long long*)nullptr);
+    else {
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kThreads), 0, s,
+                               static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
+                               static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, tn.thr, tn.dbg);
+        };
+        if (tn.dbg != nullptr) go(attn_fwd_mfma_pp_kernel<T, D, true, 0>);
+        else if (tn.opt == 1) go(attn_fwd_mfma_pp_kernel<T, D, false, 1>);
+        else go(attn_fwd_mfma_pp_kernel<T, D, false, 0>);
+    }
     return check_launch("attn_fwd_mfma");
 }
 

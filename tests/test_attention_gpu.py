@@ -153,6 +153,24 @@ def test_rescale_branch_is_forced(mfa, dtype, d):
     assert _maxdiff(out.float().cpu().numpy(), ref) <= LP_ATOL
 
 
+@pytest.mark.parametrize("env", [{"MYFA_ATTN_THR": "0"}, {"MYFA_ATTN_THR": "8"}, {"MYFA_ATTN_VARIANT": "0"}])
+@pytest.mark.parametrize("dtype,d", [(torch.bfloat16, 128), (torch.float16, 64)])
+def test_schedules_and_deferred_max_agree(mfa, monkeypatch, env, dtype, d):
+    """The two kernel schedules and the deferred-max threshold (0 = textbook rescale at every
+    growth of a row max, 8 = the default) are implementation choices: each must meet the oracle,
+    on random data and on data that forces large, late jumps of the row max."""
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)      # read by the library at every launch
+    torch.manual_seed(1)
+    N = 1000
+    q, k, v = (torch.randn(2, 2, N, d) for _ in range(3))
+    for row, key in [(0, 130), (5, 999), (31, 64), (32, 65), (100, 300), (255, 575), (256, 1), (999, 998)]:
+        k[:, :, key] = q[:, :, row] * 3.0
+    out = mfa.flash_attn_fwd(q.cuda().to(dtype), k.cuda().to(dtype), v.cuda().to(dtype), scale=1.0)
+    ref = ref_cpu.attention_bhnd(_rounded(q, dtype), _rounded(k, dtype), _rounded(v, dtype), scale=1.0)
+    assert _maxdiff(out.float().cpu().numpy(), ref) <= LP_ATOL
+
+
 def _sampled_check(mfa, c_oracle, B, H, N, d, dtype, scale, heads, nrows, seed=1):
     torch.manual_seed(seed)
     q, k, v = (torch.randn(B, H, N, d, dtype=dtype, device="cuda") for _ in range(3))
