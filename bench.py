@@ -173,7 +173,16 @@ def main():
 
     B, H, N, d, dtype = WORKLOADS[args.workload]
     scale = d ** -0.5 if args.scale == "rsqrt_d" else 1.0
-    wall, mean_ms, med_ms, _ = bench_attention(mfa, B, H, N, d, dtype, args.steps, args.warmup, world, scale)
+    wall, mean_ms, med_ms, (_, _, _, out) = bench_attention(mfa, B, H, N, d, dtype, args.steps, args.warmup, world, scale)
+    # Verification only, outside the timed region: every rank's per-head output checksums are
+    # gathered over RCCL (xGMI); all ranks must end up with the same, finite table.
+    from my_flash_attn_cuda import sharding
+    torch.cuda.synchronize()
+    tg = time.perf_counter()
+    table = sharding.gather_head_checksums(out.reshape(1, B * H, N, d), world * B * H, rank, world)
+    torch.cuda.synchronize()
+    gather_ms = (time.perf_counter() - tg) * 1e3
+    assert bool(torch.isfinite(table).all()) and table.shape == (world * B * H, 2)
     flops = attn_flops(B, H, N, d)
     value = world * args.steps * flops / wall / 1e12
     achieved = flops / (mean_ms * 1e-3) / 1e12
@@ -199,6 +208,7 @@ def main():
                      "kernel": "attn_fwd_mfma_pp_kernel", "launch_ms_mean": round(mean_ms, 4),
                      "launch_ms_median": round(med_ms, 4), "flops_per_launch": flops},
     }
+    result["verify"] = {"gathered_head_checksums": int(table.shape[0]), "gather_ms_untimed_path": round(gather_ms, 3)}
     if rank == 0 and world == 1 and not args.no_extras:
         result["softmax_sweep"] = bench_softmax_sweep(mfa)
         result["cpu_baseline"] = cpu_baseline(B, H, N, d, scale)
