@@ -26,9 +26,12 @@ constexpr float kLog2e = 1.4426950408889634f;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int VW>
+template <int VW, bool NT = true>
 __device__ __forceinline__ void vload(float (&dst)[VW], const float* p) {
-    if constexpr (VW == 4) {
+    if constexpr (VW == 4 && !NT) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+        dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2]; dst[3] = t[3];
+    } else if constexpr (VW == 4) {
         const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
         dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2]; dst[3] = t[3];
     } else {
@@ -36,9 +39,13 @@ __device__ __forceinline__ void vload(float (&dst)[VW], const float* p) {
     }
 }
 
-template <int VW>
+template <int VW, bool NT = true>
 __device__ __forceinline__ void vstore(float* p, const float (&src)[VW]) {
-    if constexpr (VW == 4) {
+    if constexpr (VW == 4 && !NT) {
+        f32x4 t;
+        t[0] = src[0]; t[1] = src[1]; t[2] = src[2]; t[3] = src[3];
+        *reinterpret_cast<f32x4*>(p) = t;
+    } else if constexpr (VW == 4) {
         f32x4 t;
         t[0] = src[0]; t[1] = src[1]; t[2] = src[2]; t[3] = src[3];
         __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
@@ -64,7 +71,7 @@ __device__ __forceinline__ float rowgroup_reduce(float wave_val, float* slot, in
     }
 }
 
-template <int TPR, int V, int VW>
+template <int TPR, int V, int VW, int NTM = 3, int MAP = 0>
 __global__ void __launch_bounds__((TPR < 256 ? 256 : TPR))
 softmax_rows_reg(const float* __restrict__ in, float* __restrict__ out, int64_t h, int64_t w) {
     constexpr int BLOCK = TPR < 256 ? 256 : TPR;
@@ -84,13 +91,19 @@ softmax_rows_reg(const float* __restrict__ in, float* __restrict__ out, int64_t 
     float* slot = scratch + row_in_blk * NW;
     const int wave_in_row = t >> 6;
 
+    // item index of (v, thread): MAP 0 interleaves the threads of the row (item v*TPR + t);
+    // MAP 1 gives each wave V consecutive 64-item pieces (a contiguous V KiB at VW = 4)
+    auto item = [&](int v) -> int64_t {
+        if constexpr (MAP == 0) return (int64_t)v * TPR + t;
+        else return ((int64_t)(t >> 6) * V + v) * 64 + (t & 63);
+    };
     float x[V][VW];
     float mx = -INFINITY;
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-        const int64_t col = ((int64_t)v * TPR + t) * VW;
+        const int64_t col = item(v) * VW;
         if (col < w) {
-            vload<VW>(x[v], src + col);
+            vload<VW, (NTM & 1) != 0>(x[v], src + col);
         } else {
 #pragma unroll
             for (int c = 0; c < VW; ++c) x[v][c] = -INFINITY;
@@ -115,11 +128,11 @@ softmax_rows_reg(const float* __restrict__ in, float* __restrict__ out, int64_t 
     const float inv = 1.0f / sum;
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-        const int64_t col = ((int64_t)v * TPR + t) * VW;
+        const int64_t col = item(v) * VW;
         if (col < w) {
 #pragma unroll
             for (int c = 0; c < VW; ++c) x[v][c] *= inv;
-            vstore<VW>(dst + col, x[v]);
+            vstore<VW, (NTM & 2) != 0>(dst + col, x[v]);
         }
     }
 }
@@ -173,18 +186,31 @@ softmax_rows_stream(const float* __restrict__ in, float* __restrict__ out, int64
     }
 }
 
+// One launch configuration of the register-resident kernel.
+//   map : 0 interleaved items, 1 wave-contiguous items
+//   nt  : bit 0 non-temporal loads, bit 1 non-temporal stores
+//   pad : unused dynamic LDS, only there to cap the workgroups per CU
+struct Shape { int tpr, v, map, nt; unsigned pad; };
+
 template <int TPR, int V, int VW>
-void launch_reg(const float* in, float* out, int64_t h, int64_t w, hipStream_t s) {
+void launch_reg(const float* in, float* out, int64_t h, int64_t w, hipStream_t s, const Shape& sh) {
     constexpr int BLOCK = TPR < 256 ? 256 : TPR;
     constexpr int RPB = BLOCK / TPR;
-    hipLaunchKernelGGL((softmax_rows_reg<TPR, V, VW>), dim3((unsigned)cdiv(h, RPB)), dim3(BLOCK), 0, s,
-                       in, out, h, w);
+    const dim3 g((unsigned)cdiv(h, RPB)), b(BLOCK);
+    if constexpr (VW == 4) {
+        if (sh.map == 1 && sh.nt == 2) hipLaunchKernelGGL((softmax_rows_reg<TPR, V, VW, 2, 1>), g, b, sh.pad, s, in, out, h, w);
+        else if (sh.map == 1)          hipLaunchKernelGGL((softmax_rows_reg<TPR, V, VW, 3, 1>), g, b, sh.pad, s, in, out, h, w);
+        else if (sh.nt == 2)           hipLaunchKernelGGL((softmax_rows_reg<TPR, V, VW, 2, 0>), g, b, sh.pad, s, in, out, h, w);
+        else                           hipLaunchKernelGGL((softmax_rows_reg<TPR, V, VW, 3, 0>), g, b, sh.pad, s, in, out, h, w);
+    } else {
+        hipLaunchKernelGGL((softmax_rows_reg<TPR, V, VW, 3, 0>), g, b, sh.pad, s, in, out, h, w);
+    }
 }
 
 template <int VW>
-bool dispatch_reg(const float* in, float* out, int64_t h, int64_t w, hipStream_t s, int tpr, int v) {
+bool dispatch_reg(const float* in, float* out, int64_t h, int64_t w, hipStream_t s, const Shape& sh) {
 #define MYFA_CASE(T, VV) \
-    if (tpr == T && v == VV) { launch_reg<T, VV, VW>(in, out, h, w, s); return true; }
+    if (sh.tpr == T && sh.v == VV) { launch_reg<T, VV, VW>(in, out, h, w, s, sh); return true; }
     MYFA_CASE(64, 1) MYFA_CASE(64, 2) MYFA_CASE(64, 4) MYFA_CASE(64, 8)
     MYFA_CASE(256, 1) MYFA_CASE(256, 2) MYFA_CASE(256, 4) MYFA_CASE(256, 8)
     MYFA_CASE(512, 2) MYFA_CASE(512, 4) MYFA_CASE(512, 8)
@@ -193,20 +219,25 @@ bool dispatch_reg(const float* in, float* out, int64_t h, int64_t w, hipStream_t
     return false;
 }
 
-// Picks threads-per-row and items-per-thread for `items` = w / VW items per row.
-// Small rows: one wave per row, four rows per workgroup (no barrier at all).
-// Larger rows: enough threads that each holds at most 8 items (32 floats).
-void choose_shape(int64_t items, int* tpr, int* v) {
-    struct Opt { int tpr, v; };
-    static const Opt table[] = {
-        {64, 1}, {64, 2}, {64, 4}, {64, 8},      // up to 512 items (w <= 2048 at VW=4)
-        {256, 4}, {256, 8},                      // up to 2048 items (w <= 8192)
-        {512, 8},                                // up to 4096 items (w <= 16384)
-        {1024, 8},                               // up to 8192 items (w <= 32768)
-    };
-    for (const Opt& o : table)
-        if ((int64_t)o.tpr * o.v >= items) { *tpr = o.tpr; *v = o.v; return; }
-    *tpr = 0; *v = 0;
+// Picks the launch configuration for `items` = w / VW items per row of an h-row matrix.
+// Small rows: one wave per row, four rows per workgroup (no barrier at all).  Larger rows:
+// choices measured on MI355X at n x n, n = 4096 ... 32768 (tools/sweep_softmax*.py): many
+// threads with few items each, wave-contiguous items, and -- for the two largest -- fewer
+// resident waves than the register count would allow (at w = 16384 half of a 1024-thread
+// workgroup's waves hold only padding; at 32768 unused LDS caps the workgroups per CU).
+// Tensors that fit the Infinity Cache are read with plain loads, larger ones streamed
+// with non-temporal loads; stores are always non-temporal.
+Shape choose_shape(int64_t items, int64_t tensor_bytes) {
+    Shape sh{0, 0, 0, tensor_bytes <= (128LL << 20) ? 2 : 3, 0};
+    if (items <= 64)        { sh.tpr = 64;   sh.v = 1; }
+    else if (items <= 128)  { sh.tpr = 64;   sh.v = 2; }
+    else if (items <= 256)  { sh.tpr = 64;   sh.v = 4; }
+    else if (items <= 512)  { sh.tpr = 64;   sh.v = 8; }
+    else if (items <= 1024) { sh.tpr = 512;  sh.v = 2; sh.map = 1; }
+    else if (items <= 2048) { sh.tpr = 1024; sh.v = 2; sh.map = 1; }
+    else if (items <= 4096) { sh.tpr = 1024; sh.v = 8; sh.map = 1; }
+    else if (items <= 8192) { sh.tpr = 1024; sh.v = 8; sh.pad = 27000; }
+    return sh;
 }
 
 }  // namespace
@@ -219,15 +250,15 @@ int softmax_f32(const float* in, float* out, int64_t h, int64_t w, hipStream_t s
     const bool vec4 = (w % 4 == 0) && (reinterpret_cast<uintptr_t>(in) % 16 == 0) &&
                       (reinterpret_cast<uintptr_t>(out) % 16 == 0);
     const int vw = vec4 ? 4 : 1;
-    int tpr = 0, v = 0;
-    choose_shape(w / vw, &tpr, &v);
-    // MYFA_SOFTMAX_SHAPE="tpr,v" overrides the choice (benchmark sweeps only).
+    Shape sh = choose_shape(w / vw, h * w * 4);
+    // MYFA_SOFTMAX_SHAPE="tpr,v[,map[,nt[,pad]]]" overrides the choice (benchmark sweeps only).
     if (const char* e = std::getenv("MYFA_SOFTMAX_SHAPE")) {
-        int a = 0, b = 0;
-        if (std::sscanf(e, "%d,%d", &a, &b) == 2 && (int64_t)a * b * vw >= w) { tpr = a; v = b; }
+        Shape o{0, 0, 0, 3, 0};
+        const int n = std::sscanf(e, "%d,%d,%d,%d,%u", &o.tpr, &o.v, &o.map, &o.nt, &o.pad);
+        if (n >= 2 && (int64_t)o.tpr * o.v * vw >= w) sh = o;
     }
     bool done = false;
-    if (tpr) done = vec4 ? dispatch_reg<4>(in, out, h, w, s, tpr, v) : dispatch_reg<1>(in, out, h, w, s, tpr, v);
+    if (sh.tpr) done = vec4 ? dispatch_reg<4>(in, out, h, w, s, sh) : dispatch_reg<1>(in, out, h, w, s, sh);
     if (!done) {
         if (vec4) hipLaunchKernelGGL(softmax_rows_stream<4>, dim3((unsigned)h), dim3(1024), 0, s, in, out, h, w);
         else      hipLaunchKernelGGL(softmax_rows_stream<1>, dim3((unsigned)h), dim3(1024), 0, s, in, out, h, w);
