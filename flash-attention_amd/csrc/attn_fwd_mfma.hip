@@ -344,7 +344,7 @@ template <int D> __device__ __forceinline__ constexpr int img_off(int row, int c
     return 16 * D * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
 }
 
-template <typename T, int D, bool STAMP = false, int OPT = 0>
+template <typename T, int D, bool STAMP = false>
 __global__ void __launch_bounds__(kThreads, 2)
 attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* __restrict__ Vg,
                         T* __restrict__ Og, float* __restrict__ LSEg, int N, int nqblk, int nwg,
@@ -360,7 +360,7 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
     constexpr int LPT = kBKV * CPR / kThreads;
     static_assert(LPT >= 1, "tile smaller than one load per thread");
 
-    __shared__ __attribute__((aligned(16))) char lds[6 * TILE_B];   // K ring of 3, V ring of 3
+    __shared__ __attribute__((aligned(16))) char lds[7 * TILE_B];   // K ring of 4, V ring of 3
 
     int lid;
     {
@@ -370,6 +370,8 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
     const int head = lid / nqblk;
     const int q0 = (lid - head * nqblk) * kBQ;
 
+    unsigned long long t_kernel0 = 0, t_loop0 = 0, t_loop1 = 0;
+    if constexpr (STAMP) t_kernel0 = stamp();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -406,16 +408,20 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
     }
     // (The host pass of hipcc silently drops a kernel whose body names this builtin, and the
     // launch stub with it; the body only exists in the device pass.)
-    auto fetch = [&](const __amdgpu_buffer_rsrc_t& rs, int tile, int lds_byte) __attribute__((always_inline)) {
+    auto fetch_piece = [&](const __amdgpu_buffer_rsrc_t& rs, int tile, int lds_byte, int i) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-        for (int i = 0; i < LPT; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + lds_byte + 1024 * (wave_u * LPT + i)),
-                                                     16, st_goff[i], tile * TILE_B, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + lds_byte + 1024 * (wave_u * LPT + i)),
+                                                 16, st_goff[i], tile * TILE_B, 0, 0);
 #endif
     };
-    auto fetch_k = [&](int tile, int slot) __attribute__((always_inline)) { fetch(krs, tile, slot * TILE_B); };
-    auto fetch_v = [&](int tile, int slot) __attribute__((always_inline)) { fetch(vrs, tile, (3 + slot) * TILE_B); };
+    auto fetch_k = [&](int tile, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) fetch_piece(krs, tile, slot * TILE_B, i);
+    };
+    auto fetch_v = [&](int tile, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) fetch_piece(vrs, tile, (4 + slot) * TILE_B, i);
+    };
 
     // ---- per-lane bases of the fragment reads (everything else is an immediate)
     // K row read, key block kb, k-step ks: row = 32kb + r, chunk = 2ks + h
@@ -458,16 +464,25 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
         a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
         return a;
     };
-    // The matrix phase as one software-pipelined stream: the fragment of MFMA i + FW is
-    // requested when MFMA i issues.  [FIRST, LAST) selects QK only, PV only, or both.
-    // kslot / vslot: ring slots (wave-uniform) of the K and V tiles read.
-    auto mma_stream = [&](int kslot, int vslot, auto first_, auto last_) __attribute__((always_inline)) {
+    // The matrix phase is one software-pipelined stream of MFMAs: the LDS fragment of MFMA
+    // i + FW is requested when MFMA i issues (an LDS read issued right before its MFMA costs
+    // the whole LDS latency per MFMA).  The first FW requests (`prefill`) are made at the end
+    // of the PREVIOUS vector phase, before the phase barrier, so the stream starts without
+    // a bubble; the window registers carry them across the barrier.
+    // [FIRST, LAST) selects QK only, PV only, or both; kslot / vslot are ring slots.
+    s16x8 win[FW];
+    auto prefill = [&](int kslot, int vslot, auto first_, auto last_) __attribute__((always_inline)) {
         constexpr int FIRST = decltype(first_)::value, LAST = decltype(last_)::value;
-        const int kbyte = kslot * TILE_B, vbyte = (3 + vslot) * TILE_B;
-        s16x8 win[FW];
+        const int kbyte = kslot * TILE_B, vbyte = (4 + vslot) * TILE_B;
 #pragma unroll
         for (int i = FIRST; i < FIRST + FW; ++i)
             if (i < LAST) win[(i - FIRST) % FW] = frag(kbyte, vbyte, i);
+    };
+    // `after(i)` runs right behind MFMA i (used to tuck the LDS-DMA issues of the next tiles
+    // under the last MFMAs, where no fragment request is left to issue).
+    auto mma_stream = [&](int kslot, int vslot, auto first_, auto last_, auto&& after) __attribute__((always_inline)) {
+        constexpr int FIRST = decltype(first_)::value, LAST = decltype(last_)::value;
+        const int kbyte = kslot * TILE_B, vbyte = (4 + vslot) * TILE_B;
         if constexpr (FIRST < NQ) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -480,12 +495,14 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
             if (i < NQ) s[i / KS] = M::run(a, qf[i % KS], s[i / KS]);
             else o[(i - NQ) % DB] = M::run(a, pb[(i - NQ) / DB], o[(i - NQ) % DB]);
             if (i + FW < LAST) win[(i - FIRST) % FW] = frag(kbyte, vbyte, i + FW);
+            after(i);
             // pin the order: left alone, the scheduler sinks every read to just before its MFMA
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    auto nothing = [](int) __attribute__((always_inline)) {};
 
-    unsigned long long cyc_x1 = 0, cyc_x2 = 0;
+    [[maybe_unused]] unsigned long long cyc_x1 = 0, cyc_x2 = 0;
     auto softmax = [&](int kv0) __attribute__((always_inline)) {
         unsigned long long s1 = 0, s2 = 0;
         if (kv0 + kBKV > N) {
@@ -542,43 +559,59 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
         asm volatile("" ::: "memory");
     };
 
-    // ---- prologue: K(0), V(0), K(1) into LDS.  Every fetch in this kernel is unconditional
+    // ---- prologue: K(0..2), V(0..1) into LDS.  Every fetch in this kernel is unconditional
     // (tiles past the end read zeros into a slot nobody reads again).
     fetch_k(0, 0);
     fetch_v(0, 0);
     fetch_k(1, 1);
+    fetch_k(2, 2);
+    fetch_v(1, 1);
     dma_wait();
     __syncthreads();
 
-    mma_stream(0, 0, IC<0>{}, IC<NQ>{});     // S(0) = K(0) Q^T
+    prefill(0, 0, IC<0>{}, IC<NQ>{});
+    mma_stream(0, 0, IC<0>{}, IC<NQ>{}, nothing);     // S(0) = K(0) Q^T
     if (grp) __syncthreads();
-    fetch_k(2, 2);
-    fetch_v(1, 1);
     softmax(0);
+    prefill(1, 0, IC<0>{}, IC<NQ + NP>{});   // first fragments of M(0): K(1), complete since the prologue
     phase_barrier();
 
+    // Ring bookkeeping (wave-uniform): tile u of K lives in slot u % 4, of V in slot u % 3.
+    // The fetches of K(w+3) and V(w+2) are issued under the last MFMAs of M(w), after the
+    // last fragment request of that phase (an LDS-DMA issue costs the issuing wave ~100
+    // cycles in a vector phase and next to nothing in the shadow of an MFMA).  Their slots
+    // held K(w-1) and V(w-1), last read by M(w-2) / M(w-1), which for either half ended at
+    // least one barrier before.  Every wave waits for its own fetches (dma_wait) at the end
+    // of its X(w+1); the first readers are the prefill at the end of X(w+2) (K) and M(w+2)
+    // (V), which for the leading half come one barrier after the lagging half's X(w+1).
     unsigned long long cyc_m = 0, cyc_mw = 0, cyc_x = 0, cyc_xw = 0, cyc_mm = 0;
-    int s0 = 0, s1 = 1, s2 = 2;      // t % 3, (t+1) % 3, (t+2) % 3
+    int k1 = 1, v0 = 0;              // (t+1) % 4, t % 3
+    if constexpr (STAMP) t_loop0 = stamp();
     for (int t = 0; t + 1 < T_; ++t) {
         unsigned long long ta = 0, tb = 0, tc = 0, td = 0, te = 0;
         if constexpr (STAMP) ta = stamp();
-        // ---- M(t): reads K(t+1), V(t).  This wave's fetches of them were issued two
-        // vector phases ago; make sure they have landed before the barrier that ends M(t),
-        // which is what tells the other waves that this wave's share is in place.
-        dma_wait();
-        // the matrix stream outranks the partner wave's vector work for the shared issue port
-        if constexpr (OPT & 1) __builtin_amdgcn_s_setprio(1);
-        mma_stream(s1, s0, IC<0>{}, IC<NQ + NP>{});
-        if constexpr (OPT & 1) __builtin_amdgcn_s_setprio(0);
+        const int k0 = (k1 + 3) & 3;             // t % 4
+        const int k2 = (k1 + 1) & 3;             // (t+2) % 4
+        const int k3 = (k1 + 2) & 3;             // (t+3) % 4
+        const int v1 = v0 == 2 ? 0 : v0 + 1;     // (t+1) % 3
+        const int v2 = v1 == 2 ? 0 : v1 + 1;     // (t+2) % 3
+        (void)k0;
+        // ---- M(t): S(t+1) = K(t+1) Q^T ; O += V(t)^T P(t)^T ; fetch K(t+3), V(t+2)
+        mma_stream(k1, v0, IC<0>{}, IC<NQ + NP>{}, [&](int i) __attribute__((always_inline)) {
+            constexpr int L0 = NQ + NP - FW;     // no fragment requests from here on
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) {
+                if (i == L0 + 2 * j)     fetch_piece(krs, t + 3, k3 * TILE_B, j);
+                if (i == L0 + 2 * j + 1) fetch_piece(vrs, t + 2, (4 + v2) * TILE_B, j);
+            }
+        });
         if constexpr (STAMP) tb = stamp();
-        __syncthreads();
+        phase_barrier();                         // the fetches just issued stay in flight across it
         if constexpr (STAMP) tc = stamp();
-        // ---- X(t+1): fetch K(t+3) into the slot K(t) has left (last read in M(t-1)) and
-        // V(t+2) into the slot V(t-1) has left; they are first read in M(t+2) / M(t+1),
-        // at least two barriers from now, and the barrier below must not wait for them.
-        fetch_k(t + 3, s0);
-        fetch_v(t + 2, s2);
+        // ---- X(t+1)
         softmax((t + 1) * kBKV);
+        dma_wait();                              // this wave's share of K(t+3), V(t+2) is in LDS
+        prefill(k2, v1, IC<0>{}, IC<NQ + NP>{}); // first fragments of M(t+1): K(t+2)
         if constexpr (STAMP) td = stamp();
         phase_barrier();
         if constexpr (STAMP) {
@@ -586,23 +619,23 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
             cyc_mm += tb - ta; cyc_m += tb - ta; cyc_mw += tc - tb;
             cyc_x += td - tc; cyc_xw += te - td;
         }
-        const int n = s0; s0 = s1; s1 = s2; s2 = n;
+        k1 = k2; v0 = v1;
     }
+    if constexpr (STAMP) t_loop1 = stamp();
+    prefill(0, v0, IC<NQ>{}, IC<NQ + NP>{});
+    mma_stream(0, v0, IC<NQ>{}, IC<NQ + NP>{}, nothing);   // M(T-1): O += V(T-1)^T P^T
     dma_wait();
-    mma_stream(0, s0, IC<NQ>{}, IC<NQ + NP>{});   // M(T-1): O += V(T-1)^T P^T
     if (grp == 0) __syncthreads();   // the leading half meets the lagging half's last barrier
-
-    if constexpr (STAMP) {
-        if (dbg != nullptr && (wave == 0 || wave == 4) && lane == 0) {
-            unsigned long long* d = dbg + (size_t)blockIdx.x * 14 + (wave >> 2) * 7;
-            d[0] = cyc_m; d[1] = cyc_mw; d[2] = cyc_x; d[3] = cyc_xw; d[4] = cyc_mm; d[5] = cyc_x1; d[6] = cyc_x2;
-        }
-    }
 
     const float ltot = half_exchange_sum(l);
     const float inv = 1.0f / ltot;
-    if (qrow < N) {
-        T* orow = Og + hoff + (size_t)qrow * D;
+    {
+        // O leaves through LDS so that it is stored as whole rows: each wave parks its 32 x D
+        // tile in its own region (rows padded by 16 bytes against bank conflicts), then 64/CPR
+        // rows go out per store instruction, 16 bytes per lane, each row contiguous.
+        constexpr int OROW_B = D * 2 + 16;
+        __syncthreads();                         // every wave is done with the K/V rings
+        char* obuf = lds + wave * (32 * OROW_B);
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -610,20 +643,37 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
                 vec4 w;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) w[j] = (T)(o[db][4 * g + j] * inv);
-                *reinterpret_cast<vec4*>(orow + 32 * db + 8 * g + 4 * h) = w;
+                *reinterpret_cast<vec4*>(obuf + r * OROW_B + (32 * db + 8 * g + 4 * h) * 2) = w;
             }
-        if (LSEg != nullptr && h == 0)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own writes only: the region is per wave
+        constexpr int RPI = 64 / CPR;            // rows per store instruction
+        const int orow0 = q0 + wave * 32;
+#pragma unroll
+        for (int k2 = 0; k2 < 32 / RPI; ++k2) {
+            const int row = k2 * RPI + lane / CPR, ch = lane % CPR;
+            const u32x4 val = *reinterpret_cast<const u32x4*>(obuf + row * OROW_B + ch * 16);
+            if (orow0 + row < N)
+                *reinterpret_cast<u32x4*>(Og + hoff + (size_t)(orow0 + row) * D + ch * 8) = val;
+        }
+        if (LSEg != nullptr && h == 0 && qrow < N)
             LSEg[(size_t)head * N + qrow] = (m + __builtin_amdgcn_logf(ltot)) * 0.6931471805599453f;
     }
+    if constexpr (STAMP) {
+        if (dbg != nullptr && (wave == 0 || wave == 4) && lane == 0) {
+            unsigned long long* d = dbg + (size_t)blockIdx.x * 14 + (wave >> 2) * 7;
+            d[0] = cyc_m; d[1] = cyc_mw; d[2] = cyc_x; d[3] = cyc_xw; d[4] = cyc_mm; d[5] = t_loop1 - t_loop0; d[6] = stamp() - t_kernel0;
+        }
+    }
+
 }
 
 // Benchmark-only knobs, read at every launch so one process can A/B them:
 // MYFA_ATTN_VARIANT (0 = one-barrier loop, 1 = ping-pong, the default) and
 // MYFA_ATTN_THR (deferred-max threshold in log2 units, default 8; 0 = rescale whenever a max grows).
-struct Tuning { int variant; float thr; unsigned long long* dbg; int opt; };
+struct Tuning { int variant; float thr; unsigned long long* dbg; };
 Tuning tuning() {
-    Tuning x{1, 8.f, nullptr, 0};
-    if (const char* e = std::getenv("MYFA_ATTN_OPT")) x.opt = std::atoi(e);   // experimental build variants
+    Tuning x{1, 8.f, nullptr};
     // MYFA_ATTN_DBG = device address (decimal) of a 14 * nwg u64 buffer: selects the stamped build
     if (const char* e = std::getenv("MYFA_ATTN_DBG")) x.dbg = reinterpret_cast<unsigned long long*>(std::strtoull(e, nullptr, 10));
     if (const char* e = std::getenv("MYFA_ATTN_VARIANT")) x.variant = std::atoi(e);
@@ -649,9 +699,8 @@ int launch(const void* q, const void* k, const void* v, void* o, float* lse,
                                static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
                                static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, tn.thr, tn.dbg);
         };
-        if (tn.dbg != nullptr) go(attn_fwd_mfma_pp_kernel<T, D, true, 0>);
-        else if (tn.opt == 1) go(attn_fwd_mfma_pp_kernel<T, D, false, 1>);
-        else go(attn_fwd_mfma_pp_kernel<T, D, false, 0>);
+        if (tn.dbg != nullptr) go(attn_fwd_mfma_pp_kernel<T, D, true>);
+        else go(attn_fwd_mfma_pp_kernel<T, D, false>);
     }
     return check_launch("attn_fwd_mfma");
 }
