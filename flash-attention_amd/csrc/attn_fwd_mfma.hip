@@ -345,7 +345,7 @@ template <int D> __device__ __forceinline__ constexpr int img_off(int row, int c
 }
 
 template <typename T, int D, bool STAMP = false>
-__global__ void __launch_bounds__(kThreads, 2)
+__global__ void __launch_bounds__(kThreads, D == 64 ? 4 : 2)
 attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* __restrict__ Vg,
                         T* __restrict__ Og, float* __restrict__ LSEg, int N, int nqblk, int nwg,
                         float sl2, float thr, unsigned long long* __restrict__ dbg = nullptr) {
@@ -445,7 +445,7 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
     f32x16 s[2];
     vec8 pb[4];
 
-    constexpr int NQ = 2 * KS, NP = 4 * DB, FW = 8;
+    constexpr int NQ = 2 * KS, NP = 4 * DB, FW = D == 64 ? 4 : 8;
     // fragment i of the matrix phase: i < NQ: K fragment (kb = i / KS, ks = i % KS) of K slot
     // KSLOT; otherwise V fragment (kb, st, db) of V slot VSLOT.  `i` is a constant after
     // unrolling, so each address is a per-lane base plus an immediate.
@@ -662,7 +662,7 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
     if constexpr (STAMP) {
         if (dbg != nullptr && (wave == 0 || wave == 4) && lane == 0) {
             unsigned long long* d = dbg + (size_t)blockIdx.x * 14 + (wave >> 2) * 7;
-            d[0] = cyc_m; d[1] = cyc_mw; d[2] = cyc_x; d[3] = cyc_xw; d[4] = cyc_mm; d[5] = t_loop1 - t_loop0; d[6] = stamp() - t_kernel0;
+            d[0] = cyc_m; d[1] = cyc_mw; d[2] = cyc_x; d[3] = cyc_xw; d[4] = cyc_mm; d[5] = t_loop0 - t_kernel0; d[6] = stamp() - t_loop1;
         }
     }
 

@@ -18,6 +18,6 @@ for _ in range(3):
 torch.cuda.synchronize()
 x = dbg.view(nwg, 2, 7).double().cpu()
 T = N // 64
-names = ["M body", "M barrier wait", "X body", "X barrier wait", "M mfma part", "loop total/tile", "kernel total/tile"]
+names = ["M body", "M barrier wait", "X body", "X barrier wait", "M mfma part", "prologue/64", "epilogue/64"]
 for g in range(2):
     print(f"wave {4*g}: " + "  ".join(f"{n}: {x[:, g, i].median().item() / T:8.1f}" for i, n in enumerate(names)) + "  (cycles per tile, median over WGs)")
