@@ -18,6 +18,11 @@ collective on the timed path.  Rank 0 prints ONE JSON line:
                    against 8 TB/s HBM peak (rank 0, N=1 only)
   cpu_config1      torch CPU timings of BASELINE config 1 (softmax 1024^2, naive attention
                    N=128 d=64), for reference beside the GPU numbers
+  power_context    the same attention launch on all-ones operands, and the vendor bf16 GEMM
+                   (torch.matmul -> hipBLASLt, 8192^3) on random and all-ones operands: the chip
+                   lowers its clock under the power limit when operands are random, so these
+                   show how much of the distance to the 2.5 PFLOP/s peak is schedule and how
+                   much is the power limit any dense MFMA kernel meets on this data
 """
 import argparse
 import json
@@ -103,6 +108,36 @@ def bench_softmax_sweep(mfa, iters=20):
         res.append({"n": n, "us": round(med * 1e3, 2), "GB/s": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
         del xs, out
         torch.cuda.empty_cache()
+    return res
+
+
+def _median_ms(fn, iters=15, warm=3):
+    for _ in range(warm):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    torch.cuda.synchronize()
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in ev)
+    return ms[len(ms) // 2]
+
+
+def power_context(mfa, B, H, N, d, dtype, scale):
+    """Untimed context: same kernel on all-ones data; vendor GEMM on random / all-ones data."""
+    ones = torch.ones(B, H, N, d, dtype=dtype, device="cuda")
+    ms = _median_ms(lambda: mfa.flash_attn_fwd(ones, ones, ones, scale=scale))
+    res = {"attn_all_ones_TFLOP/s": round(attn_flops(B, H, N, d) / ms / 1e9, 1)}
+    del ones
+    n = 8192
+    for name, make in (("randn", lambda: torch.randn(n, n, device="cuda")), ("ones", lambda: torch.ones(n, n, device="cuda"))):
+        a, b = make().to(dtype), make().to(dtype)
+        ms = _median_ms(lambda: torch.matmul(a, b))
+        res[f"vendor_gemm_{n}_{name}_TFLOP/s"] = round(2.0 * n ** 3 / ms / 1e9, 1)
+        del a, b
+    torch.cuda.empty_cache()
     return res
 
 
@@ -210,6 +245,7 @@ def main():
     }
     result["verify"] = {"gathered_head_checksums": int(table.shape[0]), "gather_ms_untimed_path": round(gather_ms, 3)}
     if rank == 0 and world == 1 and not args.no_extras:
+        result["power_context"] = power_context(mfa, B, H, N, d, dtype, scale)
         result["softmax_sweep"] = bench_softmax_sweep(mfa)
         result["cpu_baseline"] = cpu_baseline(B, H, N, d, scale)
         result["cpu_config1"] = cpu_config1()

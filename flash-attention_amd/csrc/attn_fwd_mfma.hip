@@ -329,7 +329,7 @@ attn_fwd_mfma_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T
 // recurrence; thr > 0 lets P reach 2^thr.
 
 // STAMP builds are diagnostic only: they bracket the phases with s_memtime and write the
-// per-phase cycle sums of waves 0 and 4 to `dbg` (14 u64 per workgroup); never timed.
+// per-phase cycle sums of waves 0 and 4 to `dbg` (24 u64 per workgroup); never timed.
 __device__ __forceinline__ unsigned long long stamp() {
     __builtin_amdgcn_sched_barrier(0);
     unsigned long long t;
@@ -379,14 +379,9 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
     const int r = lane & 31, h = lane >> 5;
 
     const size_t hoff = (size_t)head * (size_t)N * D;
-    const T* Qh = Qg + hoff;
 
     const int qrow = q0 + wave * 32 + r;
-    const int qrow_c = qrow < N ? qrow : N - 1;
     vec8 qf[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-        qf[ks] = *reinterpret_cast<const vec8*>(Qh + (size_t)qrow_c * D + 16 * ks + 8 * h);
 
     // ---- K/V tiles go HBM/L2 -> LDS directly (buffer_load ... lds): no staging registers, no
     // ds_write pass.  One wave-instruction fills 1 KiB of LDS, lane L at base + 16 L, so the
@@ -559,20 +554,60 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
         asm volatile("" ::: "memory");
     };
 
-    // ---- prologue: K(0..2), V(0..1) into LDS.  Every fetch in this kernel is unconditional
-    // (tiles past the end read zeros into a slot nobody reads again).
+    // ---- prologue: K(0), V(0), K(1) into their ring slots, and this wave's 32 x D block of Q
+    // into a private half slot (K slots 2, 3 and V slots 1, 2 are free until the first
+    // barrier), laid out like the first 32 rows of a K tile.  Fetched this way the block is
+    // read from memory as whole 1-KiB pieces; loading the fragments straight from global
+    // memory (16 bytes per lane at a 2D-byte stride) took 3000-6000 cycles per workgroup in
+    // the address pipeline, ahead of the K/V fetches queued behind it.
+    // Every fetch in this kernel is unconditional (tiles past the end read zeros into a slot
+    // nobody reads again).
     fetch_k(0, 0);
     fetch_v(0, 0);
     fetch_k(1, 1);
-    fetch_k(2, 2);
-    fetch_v(1, 1);
+    const int qbyte = (wave_u < 2 ? 2 : wave_u < 4 ? 3 : wave_u < 6 ? 5 : 6) * TILE_B + (wave_u & 1) * (TILE_B / 2);
+    {
+        const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc((void*)(Qg + hoff), 0, head_bytes, 0x00020000);
+        const int qrow0_b = (q0 + 32 * wave) * D * 2;      // in the lane offset: it is bounds-checked
+#pragma unroll
+        for (int pc = 0; pc < TILE_B / 2 / 1024; ++pc) {
+            const int u = 64 * pc + lane;
+            const int grp8 = u / (SUB_B / 16), within = u % (SUB_B / 16);
+            const int row = 8 * grp8 + ((within & 31) >> 2);
+            const int ch = 4 * (within >> 5) + ((within & 3) ^ ((row >> 2) & 3));
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (lds_void*)(lds + qbyte + 1024 * pc), 16,
+                                                     qrow0_b + (row * D + ch * 8) * 2, 0, 0, 0);
+#endif
+        }
+    }
+    unsigned long long t_p1 = 0, t_p2 = 0, t_p3 = 0, t_p4 = 0;
+    if constexpr (STAMP) t_p1 = stamp();
     dma_wait();
+    if constexpr (STAMP) t_p2 = stamp();
+    // Q fragments (row r, chunks 2ks + h) out of the private block; the reads must have
+    // returned before the barrier, behind which K(2) and V(1) overwrite the Q blocks.
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        qf[ks] = *reinterpret_cast<const vec8*>(lds + (kbase[ks & 1] + qbyte) + 512 * (ks >> 1));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
+    if constexpr (STAMP) t_p3 = stamp();
 
     prefill(0, 0, IC<0>{}, IC<NQ>{});
-    mma_stream(0, 0, IC<0>{}, IC<NQ>{}, nothing);     // S(0) = K(0) Q^T
+    // S(0) = K(0) Q^T, with the fetches of K(2), V(1) behind its last fragment request
+    mma_stream(0, 0, IC<0>{}, IC<NQ>{}, [&](int i) __attribute__((always_inline)) {
+        constexpr int L0 = NQ - FW;
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            if (i == L0 + 2 * j)     fetch_piece(krs, 2, 2 * TILE_B, j);
+            if (i == L0 + 2 * j + 1) fetch_piece(vrs, 1, (4 + 1) * TILE_B, j);
+        }
+    });
+    if constexpr (STAMP) t_p4 = stamp();
     if (grp) __syncthreads();
     softmax(0);
+    dma_wait();                              // K(2), V(1): every wave's share is in before the barrier
     prefill(1, 0, IC<0>{}, IC<NQ + NP>{});   // first fragments of M(0): K(1), complete since the prologue
     phase_barrier();
 
@@ -661,8 +696,9 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
     }
     if constexpr (STAMP) {
         if (dbg != nullptr && (wave == 0 || wave == 4) && lane == 0) {
-            unsigned long long* d = dbg + (size_t)blockIdx.x * 14 + (wave >> 2) * 7;
+            unsigned long long* d = dbg + (size_t)blockIdx.x * 24 + (wave >> 2) * 12;
             d[0] = cyc_m; d[1] = cyc_mw; d[2] = cyc_x; d[3] = cyc_xw; d[4] = cyc_mm; d[5] = t_loop0 - t_kernel0; d[6] = stamp() - t_loop1;
+            d[7] = t_p1 - t_kernel0; d[8] = t_p2 - t_p1; d[9] = t_p3 - t_p2; d[10] = t_p4 - t_p3; d[11] = t_loop0 - t_p4;
         }
     }
 
@@ -674,7 +710,7 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
 struct Tuning { int variant; float thr; unsigned long long* dbg; };
 Tuning tuning() {
     Tuning x{1, 8.f, nullptr};
-    // MYFA_ATTN_DBG = device address (decimal) of a 14 * nwg u64 buffer: selects the stamped build
+    // MYFA_ATTN_DBG = device address (decimal) of a 24 * nwg u64 buffer: selects the stamped build
     if (const char* e = std::getenv("MYFA_ATTN_DBG")) x.dbg = reinterpret_cast<unsigned long long*>(std::strtoull(e, nullptr, 10));
     if (const char* e = std::getenv("MYFA_ATTN_VARIANT")) x.variant = std::atoi(e);
     if (const char* e = std::getenv("MYFA_ATTN_THR")) x.thr = (float)std::atof(e);

@@ -40,3 +40,19 @@ for rnd in range(2):
     for name, (q, k, v) in cases.items():
         ms = timed(q, k, v)
         print(f"{name:14s} {ms:8.4f} ms  {flops / ms / 1e9:8.1f} TF", flush=True)
+
+# Calibration: the vendor GEMM (hipBLASLt through torch.matmul) on the same box, same dtypes:
+# what a plain bf16 MFMA GEMM sustains under the same power limit, per operand data.
+n = 8192
+gflops = 2.0 * n ** 3
+for name, f in {"randn": lambda: torch.randn(n, n), "zeros": lambda: torch.zeros(n, n), "ones": lambda: torch.ones(n, n)}.items():
+    a, b = f().to(torch.bfloat16).cuda(), f().to(torch.bfloat16).cuda()
+    for _ in range(3):
+        torch.matmul(a, b)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    torch.cuda.synchronize()
+    for x, y in ev:
+        x.record(); torch.matmul(a, b); y.record()
+    torch.cuda.synchronize()
+    ms = sorted(x.elapsed_time(y) for x, y in ev)[10]
+    print(f"matmul bf16 {n}^3 {name:6s} {ms:8.4f} ms  {gflops / ms / 1e9:8.1f} TF", flush=True)

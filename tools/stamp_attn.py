@@ -9,15 +9,21 @@ B, H, N, d = 4, 32, 4096, 128
 torch.manual_seed(1)
 q, k, v = (torch.randn(B, H, N, d, dtype=torch.bfloat16, device="cuda") for _ in range(3))
 nwg = B * H * (N // 256)
-dbg = torch.zeros(nwg * 14, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(nwg * 24, dtype=torch.int64, device="cuda")
 for key, val in [kv.split("=") for kv in sys.argv[1:]]:
     os.environ["MYFA_ATTN_" + key] = val
 os.environ["MYFA_ATTN_DBG"] = str(dbg.data_ptr())
 for _ in range(3):
     mfa.flash_attn_fwd(q, k, v, scale=d ** -0.5)
 torch.cuda.synchronize()
-x = dbg.view(nwg, 2, 7).double().cpu()
+x = dbg.view(nwg, 2, 12).double().cpu()
 T = N // 64
 names = ["M body", "M barrier wait", "X body", "X barrier wait", "M mfma part", "prologue/64", "epilogue/64"]
+pro = ["to fetch issue", "fetch wait", "first barrier", "QK(0)", "X(0)+barrier(s)"]
 for g in range(2):
     print(f"wave {4*g}: " + "  ".join(f"{n}: {x[:, g, i].median().item() / T:8.1f}" for i, n in enumerate(names)) + "  (cycles per tile, median over WGs)")
+for g in range(2):
+    print(f"wave {4*g} prologue cycles (median over WGs): " + "  ".join(f"{n}: {x[:, g, 7 + i].median().item():8.0f}" for i, n in enumerate(pro))
+          + f"  total: {x[:, g, 5].median().item():8.0f}   epilogue: {x[:, g, 6].median().item():8.0f}")
+first = x[:256, 0, 5].median().item(); later = x[256:, 0, 5].median().item()
+print(f"prologue of the first 256 workgroups: {first:.0f}; of the rest: {later:.0f}")
