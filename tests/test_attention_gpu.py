@@ -125,6 +125,29 @@ def test_bhnd_f32_vs_oracle(mfa, shape):
     assert _maxdiff(lse.cpu().numpy(), ref_cpu.attention_lse(q.numpy(), k.numpy(), scale=0.5)) <= 1e-5
 
 
+@pytest.mark.parametrize("dtype,d", [(torch.bfloat16, 128), (torch.float16, 64)])
+@pytest.mark.parametrize("N", [1, 100, 191])
+def test_memory_behind_the_tensors_never_reaches_the_output(mfa, dtype, d, N):
+    """K/V tiles are fetched 64 rows at a time and up to three tiles ahead, so for the last
+    head the fetch addresses run past the end of the tensor.  Those fetches must come back as
+    zeros (buffer bounds), never as whatever lies behind: Q, K and V sit here in front of a
+    NaN-filled tail, and a single 0 * NaN in the P.V product would poison the output."""
+    B, H = 1, 2
+    torch.manual_seed(1)
+    n = B * H * N * d
+    tail = 64 * 1024
+    bufs = [torch.full((n + tail,), float("nan"), dtype=dtype, device="cuda") for _ in range(3)]
+    host = [torch.randn(B, H, N, d, dtype=torch.float32) for _ in range(3)]
+    views = []
+    for b, x in zip(bufs, host):
+        b[:n] = x.reshape(-1).to(dtype).cuda()
+        views.append(b[:n].view(B, H, N, d))
+    out = mfa.flash_attn_fwd(*views, scale=d ** -0.5)
+    assert bool(torch.isfinite(out.float()).all())
+    qr, kr, vr = (_rounded(x, dtype) for x in host)
+    assert _maxdiff(out.float().cpu().numpy(), ref_cpu.attention_bhnd(qr, kr, vr, scale=d ** -0.5)) <= LP_ATOL
+
+
 def test_bhnd_errors(mfa):
     q = torch.randn(1, 2, 64, 96, device="cuda", dtype=torch.bfloat16)
     with pytest.raises(RuntimeError, match="head dim"):
