@@ -1,4 +1,4 @@
-// Fused attention forward in float32 for any sequence length and head dim.
+// Fused attention forward in float32 for any sequence length and head dim <= 512.
 //
 //     O = softmax(scale * Q K^T) V
 //
@@ -12,194 +12,296 @@
 // relative error in the weight, and a float32 dot product of d terms of size
 // |S| ~ 30-40 is off by ~1e-5 (that is the distance between the reference's own
 // float32 result and the exact one).  To hold 1e-5 against an exact (float64)
-// oracle, the logits are accumulated in float64 (v_fma_f64) and the subtraction
-// of the row max is done in float64; the exponential, the row sum and the P.V
-// accumulation are float32.
+// oracle the logits come from the FLOAT64 matrix instruction
+// (v_mfma_f64_16x16x4_f64, inputs widened exactly), and the scaling, the
+// subtraction of the row max and the change to base 2 are done in float64; the
+// exponential, the row sum and the P.V product (v_mfma_f32_16x16x4_f32) are float32.
 //
-// Mapping.  One lane owns one query row ("query on the lane"), so row max / row
-// sum / rescale are per-lane scalars with no cross-lane traffic.  K and V
-// elements are the same for every lane of a wave, so they are fetched with
-// wave-uniform addresses (scalar loads, 16 dwords at a time) and fed to the FMAs
-// as scalar operands; Q^T lives in LDS, padded to 65 floats per row so that both
-// its fill and its per-lane reads are bank-conflict-free.  A workgroup is 4 waves
-// working on the SAME 64 queries, each taking every 4th tile of 16 keys; the four
-// partial (m, l, O) states are merged through LDS at the end.  Output columns are
-// processed in chunks of DCH per workgroup (gridDim.z chunks).
+// Mapping.  A wave owns 16 query rows and walks 16-key tiles.  Lane l = (j, g),
+// j = l & 15, g = l >> 4:
+//   S^T = K Q^T   16 keys x 16 queries per tile, d/4 steps of the f64 MFMA;
+//                 A = K[key j][dd], B = Q[query j][dd], dd = 16b + 4g + t (one float4 per
+//                 lane and 16-wide block b).  Result c[r] = S[key 4r + g][query j]: the
+//                 query sits on the lane, as in the low-precision kernel.
+//   O^T += V^T P^T  the weights p[r] feed the f32 MFMA directly as its B operand
+//                 (k index = g <-> key 4r + g, i.e. step r takes keys 4r..4r+3);
+//                 A = V[key 4r + g][64bb + 4j + t] (float4 per lane), so accumulator
+//                 4bb + t holds O[query j][64bb + 16g + 4r' + t] in register r' -- sixteen
+//                 consecutive output columns per lane, stored as four float4.
+// The running max is shared by the four lanes (g) of a query through two lane
+// exchanges per tile; the row sum stays a per-lane partial until the end.
+//
+// Parallelism.  A workgroup is QG x KS waves: QG groups of 16 queries that walk the
+// same keys together (so K/V tiles are fetched once per workgroup as far as L1 is
+// concerned) times KS interleaved shares of the key tiles, merged through LDS at
+// the end.  The host picks KS > 1 only when there are too few query groups to fill
+// the chip (the reference's single-head shapes), so no workspace is ever needed.
 #include "myfa_common.h"
 
 namespace myfa {
 namespace {
 
-constexpr int kQB = 64;    // queries per workgroup (one per lane)
-constexpr int kKT = 16;    // keys per tile
-constexpr int kNW = 4;     // waves per workgroup
-constexpr int kQPad = 65;  // padded row length of the Q^T image
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float exp_or_zero(float m_old, float m_new) {
     // exp(m_old - m_new) with the convention exp(-inf - (-inf)) = 0
-    return m_old == -INFINITY ? 0.f : expf(m_old - m_new);
+    return m_old == -INFINITY ? 0.f : __expf(m_old - m_new);
 }
 
-template <int DCH, bool KCONTIG>
-__global__ void __launch_bounds__(kNW * 64)
+template <int NB> constexpr int max_waves() { return NB <= 4 ? 16 : NB <= 8 ? 8 : 4; }
+
+// NB: padded head dim / 16 (4, 8, 16 or 32).  KT: K is given transposed ([d, N], the reference's
+// my_attention layout) instead of [N, d].  VEC: d % 4 == 0 and all bases 16-byte aligned, so rows
+// are read and written as float4; otherwise element by element.
+template <int NB, bool KT, bool VEC>
+__global__ void __launch_bounds__(max_waves<NB>() * 64)
 attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
                     const float* __restrict__ Vg, float* __restrict__ Og, float* __restrict__ LSEg,
-                    int N, int d, long long k_key_stride, long long k_d_stride,
-                    long long head_stride, float scale) {
+                    int N, int d, int QG, int KS, long long head_stride, float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NBB = NB / 4;                    // 64-wide column groups
+    constexpr bool PREFETCH = NB <= 8;             // K and V of a tile held whole, fetched ahead of use
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int q0 = blockIdx.x * kQB;
-    const int c0 = blockIdx.z * DCH;
+    const int qg = wave % QG, split = wave / QG;
+    const int j = lane & 15, g = lane >> 4;
+    // one head is addressed with 32-bit element offsets (the host checks N * d < 2^31)
     const long long hoff = (long long)blockIdx.y * head_stride;
     const float* Qh = Qg + hoff;
     const float* Kh = Kg + hoff;
     const float* Vh = Vg + hoff;
 
-    // ---- Q^T image: smem[c * 65 + row]; rows past N repeat the last valid row
-    const int nq = min(kQB, N - q0);
-    for (int idx = threadIdx.x; idx < kQB * d; idx += kNW * 64) {
-        const int row = idx / d, c = idx - row * d;
-        const int grow = q0 + (row < nq ? row : nq - 1);
-        smem[c * kQPad + row] = Qh[(long long)grow * d + c];
-    }
-    __syncthreads();
+    const int qrow = (blockIdx.x * QG + qg) * 16 + j;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+    const int ntiles = (N + 15) >> 4;
 
+    // four consecutive floats of a row (zero past column d)
+    auto row4 = [&](const float* row, int col) __attribute__((always_inline)) -> f32x4 {
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (VEC) {
+            if (col < d) x = *reinterpret_cast<const f32x4*>(row + col);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (col + t < d) x[t] = row[col + t];
+        }
+        return x;
+    };
+    // K[key][col .. col+3] in either layout
+    auto k4 = [&](int key, int col) __attribute__((always_inline)) -> f32x4 {
+        if constexpr (KT) {
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (col + t < d) x[t] = Kh[(col + t) * N + key];
+            return x;
+        } else {
+            return row4(Kh + key * d, col);
+        }
+    };
+
+    f32x4 qv[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) qv[b] = row4(Qh + qrow_c * d, 16 * b + 4 * g);
+
+    f32x4 o[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) o[b] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;
-    float acc[DCH];
-#pragma unroll
-    for (int i = 0; i < DCH; ++i) acc[i] = 0.f;
-
-    const bool dfull = (c0 + DCH <= d);
     const double dscale = (double)scale;
-    const int ntiles = (N + kKT - 1) / kKT;
 
-    for (int t = wave; t < ntiles; t += kNW) {
-        const int j0 = t * kKT;
-        const bool full = (j0 + kKT <= N);
+    // (rows past N are masked in the softmax; the clamp only keeps the address valid)
+    [[maybe_unused]] f32x4 kf[PREFETCH ? NB : 1];
+    auto load_k = [&](int kt) __attribute__((always_inline)) {
+        const int key = min(kt * 16 + j, N - 1);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) kf[b] = k4(key, 16 * b + 4 * g);
+    };
+    if constexpr (PREFETCH) load_k(min(split, ntiles - 1));
 
-        // ---- logits of 16 keys for this lane's query, float64 accumulation
-        double s[kKT];
+    for (int kt = split; kt < ntiles; kt += KS) {
+        const int key0 = kt * 16;
+        // ---- V of this tile is requested now and consumed after the logits
+        [[maybe_unused]] f32x4 vf[PREFETCH ? 4 : 1][PREFETCH ? NBB : 1];
+        if constexpr (PREFETCH) {
 #pragma unroll
-        for (int j = 0; j < kKT; ++j) s[j] = 0.0;
-        if (full) {
-            for (int c = 0; c < d; ++c) {
-                const double qv = (double)smem[c * kQPad + lane];
-                const float* kp = Kh + (long long)c * k_d_stride + (KCONTIG ? (long long)j0 : (long long)j0 * k_key_stride);
+            for (int r = 0; r < 4; ++r) {
+                const float* vrow = Vh + min(key0 + 4 * r + g, N - 1) * d;
 #pragma unroll
-                for (int j = 0; j < kKT; ++j) {
-                    const float kv = KCONTIG ? kp[j] : kp[(long long)j * k_key_stride];
-                    s[j] = fma(qv, (double)kv, s[j]);
-                }
+                for (int bb = 0; bb < NBB; ++bb) vf[r][bb] = row4(vrow, 64 * bb + 4 * j);
             }
+        }
+
+        // ---- S^T tile: float64 MFMA over the head dim
+        f64x4 c = {0.0, 0.0, 0.0, 0.0};
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)kf[b][t], (double)qv[b][t], c, 0, 0, 0);
+            // K of this wave's next tile goes into the registers just consumed; its latency
+            // is covered by the softmax and the P.V product below
+            load_k(min(kt + KS, ntiles - 1));
         } else {
-            for (int c = 0; c < d; ++c) {
-                const double qv = (double)smem[c * kQPad + lane];
-                const float* kp = Kh + (long long)c * k_d_stride;
+            const int key = min(key0 + j, N - 1);
 #pragma unroll
-                for (int j = 0; j < kKT; ++j) {
-                    const int jj = min(j0 + j, N - 1);
-                    const float kv = KCONTIG ? kp[jj] : kp[(long long)jj * k_key_stride];
-                    s[j] = fma(qv, (double)kv, s[j]);
-                }
+            for (int bb = 0; bb < NBB; ++bb) {
+                f32x4 kc[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) kc[i] = k4(key, 64 * bb + 16 * i + 4 * g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float qe = qv[4 * bb + i][t];
+                        // at 512 columns the widened copy of Q does not fit the register file
+                        // beside Q and O: widen at each use instead of once outside the loop
+                        if constexpr (NB > 16) asm volatile("" : "+v"(qe));
+                        c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)kc[i][t], (double)qe, c, 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);   // keep the chunks' loads from piling up in registers
             }
         }
 
-        double tmax = -INFINITY;
+        // ---- online softmax; c[r] is key key0 + 4r + g of query j
+        double x[4];
+        float tmax = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < kKT; ++j) {
-            s[j] = (j0 + j < N) ? s[j] * dscale : -INFINITY;
-            tmax = fmax(tmax, s[j]);
+        for (int r = 0; r < 4; ++r) {
+            x[r] = c[r] * dscale;
+            if (key0 + 4 * r + g < N) tmax = fmaxf(tmax, (float)x[r]);
         }
-        const float m_new = fmaxf(m, (float)tmax);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m, tmax);
         const float alpha = exp_or_zero(m, m_new);
-        float p[kKT];
-        float psum = 0.f;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {    // wave-uniform
+            l *= alpha;
 #pragma unroll
-        for (int j = 0; j < kKT; ++j) {
-            p[j] = expf((float)(s[j] - (double)m_new));
-            psum += p[j];
+            for (int b = 0; b < NB; ++b) o[b] *= alpha;
         }
-        l = l * alpha + psum;
         m = m_new;
+        float p[4];
 #pragma unroll
-        for (int i = 0; i < DCH; ++i) acc[i] *= alpha;
+        for (int r = 0; r < 4; ++r) {
+            const float e = (float)((x[r] - (double)m) * 1.4426950408889634);
+            p[r] = (key0 + 4 * r + g < N) ? __builtin_amdgcn_exp2f(e) : 0.f;
+            l += p[r];
+        }
 
-        // ---- O[query, c0..c0+DCH) += sum_j p_j V[j, ...]
-        if (dfull) {
+        // ---- O^T += V^T P^T
 #pragma unroll
-            for (int j = 0; j < kKT; ++j) {
-                const float* vp = Vh + (long long)min(j0 + j, N - 1) * d + c0;
+        for (int r = 0; r < 4; ++r) {
+            [[maybe_unused]] const float* vrow = Vh + min(key0 + 4 * r + g, N - 1) * d;
 #pragma unroll
-                for (int i = 0; i < DCH; ++i) acc[i] = fmaf(p[j], vp[i], acc[i]);
-            }
-        } else {
+            for (int bb = 0; bb < NBB; ++bb) {
+                f32x4 v;
+                if constexpr (PREFETCH) v = vf[r][bb];
+                else v = row4(vrow, 64 * bb + 4 * j);
 #pragma unroll
-            for (int j = 0; j < kKT; ++j) {
-                const float* vp = Vh + (long long)min(j0 + j, N - 1) * d;
-#pragma unroll
-                for (int i = 0; i < DCH; ++i) acc[i] = fmaf(p[j], vp[min(c0 + i, d - 1)], acc[i]);
+                for (int t = 0; t < 4; ++t)
+                    o[4 * bb + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[t], p[r], o[4 * bb + t], 0, 0, 0);
+                if constexpr (!PREFETCH) {
+                    if ((bb & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     }
 
-    // ---- merge the four waves' partial states: (1 -> 0, 3 -> 2), then (2 -> 0)
-    __syncthreads();   // Q^T image no longer needed; its space becomes the merge buffers
-    constexpr int kSlot = (DCH + 2) * 64;
-    auto put = [&](float* b) {
-        b[lane] = m;
-        b[64 + lane] = l;
+    // the four lanes of a query hold partial row sums over their own keys
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+
+    // ---- merge the KS key shares of each query group through LDS (share 0 collects)
+    constexpr int kSlot = (NB * 4 + 2) * 64;       // floats per parked wave state
+    if (KS > 1) {
+        if (split > 0) {
+            float* b = smem + (size_t)((split - 1) * QG + qg) * kSlot;
 #pragma unroll
-        for (int i = 0; i < DCH; ++i) b[(2 + i) * 64 + lane] = acc[i];
-    };
-    auto merge = [&](const float* b) {
-        const float m2 = b[lane], l2 = b[64 + lane];
-        const float mn = fmaxf(m, m2);
-        const float a1 = exp_or_zero(m, mn), a2 = exp_or_zero(m2, mn);
-        l = l * a1 + l2 * a2;
+            for (int e = 0; e < NB; ++e)
 #pragma unroll
-        for (int i = 0; i < DCH; ++i) acc[i] = acc[i] * a1 + b[(2 + i) * 64 + lane] * a2;
-        m = mn;
-    };
-    if (wave == 1 || wave == 3) put(smem + (wave >> 1) * kSlot);
-    __syncthreads();
-    if (wave == 0 || wave == 2) merge(smem + (wave >> 1) * kSlot);
-    __syncthreads();
-    if (wave == 2) put(smem);
-    __syncthreads();
-    if (wave == 0) {
-        merge(smem);
-        const int row = q0 + lane;
-        if (row < N) {
-            const float inv = 1.0f / l;
-            float* orow = Og + hoff + (long long)row * d;
+                for (int r = 0; r < 4; ++r) b[(4 * e + r) * 64 + lane] = o[e][r];
+            b[NB * 4 * 64 + lane] = m;
+            b[(NB * 4 + 1) * 64 + lane] = l;
+        }
+        __syncthreads();
+        if (split == 0) {
+            for (int s = 1; s < KS; ++s) {
+                const float* b = smem + (size_t)((s - 1) * QG + qg) * kSlot;
+                const float m2 = b[NB * 4 * 64 + lane], l2 = b[(NB * 4 + 1) * 64 + lane];
+                const float mn = fmaxf(m, m2);
+                const float a1 = exp_or_zero(m, mn), a2 = exp_or_zero(m2, mn);
+                l = l * a1 + l2 * a2;
 #pragma unroll
-            for (int i = 0; i < DCH; ++i)
-                if (c0 + i < d) orow[c0 + i] = acc[i] * inv;
-            if (LSEg != nullptr && blockIdx.z == 0)
-                LSEg[(long long)blockIdx.y * N + row] = m + logf(l);
+                for (int e = 0; e < NB; ++e)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[e][r] = o[e][r] * a1 + b[(4 * e + r) * 64 + lane] * a2;
+                m = mn;
+            }
         }
     }
+    if (split != 0 || qrow >= N) return;
+
+    // ---- store: accumulator 4bb + t, register r holds column 64bb + 16g + 4r + t
+    const float inv = 1.0f / l;
+    float* orow = Og + hoff + qrow * d;
+#pragma unroll
+    for (int bb = 0; bb < NBB; ++bb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = 64 * bb + 16 * g + 4 * r;
+            const f32x4 w = {o[4 * bb][r] * inv, o[4 * bb + 1][r] * inv, o[4 * bb + 2][r] * inv, o[4 * bb + 3][r] * inv};
+            if constexpr (VEC) {
+                if (col < d) *reinterpret_cast<f32x4*>(orow + col) = w;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (col + t < d) orow[col + t] = w[t];
+            }
+        }
+    if (LSEg != nullptr && g == 0) LSEg[(long long)blockIdx.y * N + qrow] = m + logf(l);
 }
 
-template <int DCH, bool KCONTIG>
+template <int NB, bool KT, bool VEC>
 int launch(const float* q, const float* k, const float* v, float* o, float* lse,
-           int64_t heads, int64_t N, int64_t d, int64_t k_key_stride, int64_t k_d_stride,
-           float scale, hipStream_t s) {
-    auto kern = attn_fwd_f32_kernel<DCH, KCONTIG>;
-    const size_t lds_floats = (size_t)max((int64_t)d * kQPad, (int64_t)2 * (DCH + 2) * 64);
-    const size_t lds_bytes = lds_floats * sizeof(float);
+           int64_t heads, int64_t N, int64_t d, float scale, hipStream_t s) {
+    auto kern = attn_fwd_f32_kernel<NB, KT, VEC>;
+    constexpr int wmax = max_waves<NB>();
+    const int64_t qgroups = cdiv(N, 16);
+    const int64_t ntiles = cdiv(N, 16);
+    // Key shares only when the query groups alone cannot fill the chip (2 waves per SIMD of
+    // 256 CUs = 2048 waves); then as many as fit the workgroup, a power of two, at most one
+    // per key tile.
+    int ks = 1;
+    while (ks < wmax && ks * 2 <= ntiles && qgroups * heads * ks < 2048) ks *= 2;
+    // Query groups per workgroup share their K/V fetches; keep at least ~2 workgroups per CU.
+    int qgn = wmax / ks;
+    while (qgn > 1 && cdiv(qgroups, qgn) * heads < 512) qgn /= 2;
+    const size_t lds_bytes = ks > 1 ? (size_t)(ks - 1) * qgn * (NB * 4 + 2) * 64 * sizeof(float) : 0;
+    if (lds_bytes > 160 * 1024)
+        return fail(MYFA_E_UNSUPPORTED, "attention (f32): merge buffer of %zu bytes exceeds LDS", lds_bytes);
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess)
             return fail(MYFA_E_LAUNCH, "attention (f32): cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
     }
-    const dim3 grid((unsigned)cdiv(N, kQB), (unsigned)heads, (unsigned)cdiv(d, DCH));
-    hipLaunchKernelGGL(kern, grid, dim3(kNW * 64), lds_bytes, s, q, k, v, o, lse, (int)N, (int)d,
-                       (long long)k_key_stride, (long long)k_d_stride, (long long)(N * d), scale);
+    const dim3 grid((unsigned)cdiv(qgroups, qgn), (unsigned)heads);
+    hipLaunchKernelGGL(kern, grid, dim3(qgn * ks * 64), lds_bytes, s, q, k, v, o, lse, (int)N, (int)d,
+                       qgn, ks, (long long)(N * d), scale);
     return check_launch("attn_fwd_f32");
+}
+
+template <int NB>
+int launch_layout(const float* q, const float* k, const float* v, float* o, float* lse,
+                  int64_t heads, int64_t N, int64_t d, bool kt, bool vec, float scale, hipStream_t s) {
+    if (kt) return vec ? launch<NB, true, true>(q, k, v, o, lse, heads, N, d, scale, s)
+                       : launch<NB, true, false>(q, k, v, o, lse, heads, N, d, scale, s);
+    return vec ? launch<NB, false, true>(q, k, v, o, lse, heads, N, d, scale, s)
+               : launch<NB, false, false>(q, k, v, o, lse, heads, N, d, scale, s);
 }
 
 }  // namespace
@@ -211,14 +313,20 @@ int attn_fwd_f32(const float* q, const float* k, const float* v, float* o, float
                  int64_t heads, int64_t N, int64_t d, int64_t k_key_stride, int64_t k_d_stride,
                  float scale, hipStream_t s) {
     if (d > 512) return fail(MYFA_E_UNSUPPORTED, "attention (f32): head dim %lld > 512", (long long)d);
-    if (N > (1LL << 30) || heads > 65535)
-        return fail(MYFA_E_UNSUPPORTED, "attention (f32): N=%lld or heads=%lld beyond the grid limits", (long long)N, (long long)heads);
-    const bool kc = (k_key_stride == 1);
-    if (d <= 32)
-        return kc ? launch<32, true>(q, k, v, o, lse, heads, N, d, k_key_stride, k_d_stride, scale, s)
-                  : launch<32, false>(q, k, v, o, lse, heads, N, d, k_key_stride, k_d_stride, scale, s);
-    return kc ? launch<64, true>(q, k, v, o, lse, heads, N, d, k_key_stride, k_d_stride, scale, s)
-              : launch<64, false>(q, k, v, o, lse, heads, N, d, k_key_stride, k_d_stride, scale, s);
+    if (N * d >= (1LL << 31) || heads > 65535)
+        return fail(MYFA_E_UNSUPPORTED, "attention (f32): N*d=%lld per head or heads=%lld beyond the kernel's limits", (long long)(N * d), (long long)heads);
+    // (with d == 1 or N == 1 the two layouts are the same bytes)
+    const bool rowmajor = (k_key_stride == d && k_d_stride == 1) || d == 1 || N == 1;
+    const bool kt = !rowmajor;
+    if (kt && !(k_key_stride == 1 && k_d_stride == N))
+        return fail(MYFA_E_UNSUPPORTED, "attention (f32): K must be [N, d] or [d, N] contiguous");
+    const bool vec = d % 4 == 0 &&
+        ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
+          reinterpret_cast<uintptr_t>(o)) % 16 == 0);
+    if (d <= 64)  return launch_layout<4>(q, k, v, o, lse, heads, N, d, kt, vec, scale, s);
+    if (d <= 128) return launch_layout<8>(q, k, v, o, lse, heads, N, d, kt, vec, scale, s);
+    if (d <= 256) return launch_layout<16>(q, k, v, o, lse, heads, N, d, kt, vec, scale, s);
+    return launch_layout<32>(q, k, v, o, lse, heads, N, d, kt, vec, scale, s);
 }
 
 }  // namespace myfa

@@ -20,13 +20,13 @@ __device__ __forceinline__ unsigned long long stamp() {
     return t;
 }
 
-enum { NONE = 0, MFMA32, MFMA16, FMA, EXP, PKFMA, PKADD, CVT, MAX3, SOFTMAX, SOFTMAX_PK, LDSR, FMA_DEP, EXP_DEP, MAX3_DEP, SOFTMAX_SKEW, SOFTMAX_BLOCK, NMODES };
+enum { NONE = 0, MFMA32, MFMA16, FMA, EXP, PKFMA, PKADD, CVT, MAX3, SOFTMAX, SOFTMAX_PK, LDSR, FMA_DEP, EXP_DEP, MAX3_DEP, SOFTMAX_SKEW, SOFTMAX_BLOCK, MFMA_F64, MFMA_F32, CVT_F64, NMODES };
 static const char* kNames[NMODES] = {"none", "mfma32x32x16", "mfma16x16x32", "v_fma", "v_exp", "v_pk_fma", "v_pk_add",
                                      "v_cvt_pk_bf16", "v_max3", "softmax(fma,exp,add)", "softmax(pk)", "ds_read_b128", "v_fma dependent", "v_exp dependent", "v_max3 dependent",
-                                     "softmax skewed", "softmax blocked"};
+                                     "softmax skewed", "softmax blocked", "mfma_f64_16x16x4", "mfma_f32_16x16x4", "v_cvt_f64_f32"};
 // instructions per outer iteration for each mode
 __host__ __device__ constexpr int per_iter(int mode) {
-    return mode == MFMA32 ? 16 : mode == MFMA16 ? 16 : mode == SOFTMAX || mode == SOFTMAX_SKEW || mode == SOFTMAX_BLOCK ? 384 : mode == SOFTMAX_PK ? 256 : mode == NONE ? 0 : mode == LDSR ? 32 : 128;
+    return mode == MFMA32 || mode == MFMA_F64 || mode == MFMA_F32 ? 16 : mode == MFMA16 ? 16 : mode == SOFTMAX || mode == SOFTMAX_SKEW || mode == SOFTMAX_BLOCK ? 384 : mode == SOFTMAX_PK ? 256 : mode == NONE ? 0 : mode == LDSR ? 32 : 128;
 }
 
 template <int MODE>
@@ -48,6 +48,23 @@ __device__ __forceinline__ float run_stream(int iters, float seed, char* lds, un
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int u = 0; u < 16; ++u) c[u & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c[u & 3], 0, 0, 0);
+        }
+        for (int u = 0; u < 4; ++u) acc += c[u][0];
+    } else if constexpr (MODE == MFMA_F64) {
+        typedef double f64x4 __attribute__((ext_vector_type(4)));
+        f64x4 c[4] = {};
+        const double a = seed, b = seed + 1.0;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) c[u & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c[u & 3], 0, 0, 0);
+        }
+        for (int u = 0; u < 4; ++u) acc += (float)c[u][0];
+    } else if constexpr (MODE == MFMA_F32) {
+        f32x4 c[4] = {};
+        const float a = seed, b = seed + 1.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) c[u & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c[u & 3], 0, 0, 0);
         }
         for (int u = 0; u < 4; ++u) acc += c[u][0];
     } else if constexpr (MODE == LDSR) {
@@ -88,6 +105,7 @@ __device__ __forceinline__ float run_stream(int iters, float seed, char* lds, un
                     asm volatile("v_exp_f32 %0, %0" : "+v"(x[k]));
                     asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x[k]));
                 }
+                if constexpr (MODE == CVT_F64) { double dd; asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(dd) : "v"(x[k])); if (u == 127) acc += (float)dd; }
                 if constexpr (MODE == FMA_DEP) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[0]) : "v"(sc), "v"(mm));
                 if constexpr (MODE == EXP_DEP) asm volatile("v_exp_f32 %0, %0" : "+v"(x[0]));
                 if constexpr (MODE == MAX3_DEP) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x[0]) : "v"(x[(k + 1) & 7]), "v"(x[(k + 2) & 7]));
@@ -178,6 +196,10 @@ int main() {
     run<NONE, SOFTMAX>(0, it, d_cyc, d_sink);
     run<NONE, SOFTMAX_PK>(0, it, d_cyc, d_sink);
     run<NONE, LDSR>(0, it, d_cyc, d_sink);
+    run<MFMA_F64, NONE>(it, 0, d_cyc, d_sink);
+    run<MFMA_F32, NONE>(it, 0, d_cyc, d_sink);
+    run<NONE, CVT_F64>(0, it, d_cyc, d_sink);
+    run<MFMA_F64, MFMA_F64>(it, it, d_cyc, d_sink);
     run<NONE, FMA_DEP>(0, it, d_cyc, d_sink);
     run<NONE, EXP_DEP>(0, it, d_cyc, d_sink);
     run<NONE, MAX3_DEP>(0, it, d_cyc, d_sink);

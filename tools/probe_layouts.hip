@@ -71,6 +71,30 @@ __global__ void k_tr(short* out) {
     for (int e = 0; e < 4; ++e) out[lane * 4 + e] = t[e];
 }
 
+// ---- 5. v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32: D[16x16] = A[16x4] B[4x16] + C
+// lane l (j = l&15, g = l>>4): a = A[j][g], b = B[g][j]; D, r = 0..3: f32 holds D[4g + r][j], f64 holds D[4r + g][j]
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ void k_mfma64(const float* A, const float* B, float* C64, float* C32) {
+    const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+    f64x4 c = {0, 0, 0, 0};
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)A[j * 4 + g], (double)B[g * 16 + j], c, 0, 0, 0);
+    f32x4 e = {0, 0, 0, 0};
+    e = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j * 4 + g], B[g * 16 + j], e, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) { C64[(4 * r + g) * 16 + j] = (float)c[r]; C32[(4 * g + r) * 16 + j] = e[r]; }
+}
+// ---- 6. chain: X[16 keys x 16 queries] from the f64 MFMA; Y[16 x 16] = A2[16 x 16 keys] . X with the
+// f32 MFMA, k-step r taking keys 4r .. 4r+3: b = (float)x[r], a = A2[j][4r + g]
+__global__ void k_chain64(const float* A, const float* B, const float* A2, float* Y) {
+    const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+    f64x4 x = {0, 0, 0, 0};
+    x = __builtin_amdgcn_mfma_f64_16x16x4f64((double)A[j * 4 + g], (double)B[g * 16 + j], x, 0, 0, 0);
+    f32x4 y = {0, 0, 0, 0};
+    for (int r = 0; r < 4; ++r)
+        y = __builtin_amdgcn_mfma_f32_16x16x4f32(A2[j * 16 + 4 * r + g], (float)x[r], y, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) Y[(4 * g + r) * 16 + j] = y[r];
+}
+
 int main() {
     int fails = 0;
     {   // 1
@@ -120,6 +144,26 @@ int main() {
             }
         }
         printf("4. ds_read_b64_tr_b16 (lane i <- column i, element e <- row e): %s (%d mismatches)\n", bad ? "FAIL" : "PASS", bad); fails += bad != 0;
+    }
+    {   // 5, 6
+        std::vector<float> a(16 * 4), b(4 * 16), a2(16 * 16), x(256), y(256), got(256), got2(256);
+        for (int m = 0; m < 16; ++m) for (int k = 0; k < 4; ++k) a[m * 4 + k] = (float)((m + 2 * k) % 7 - 3);
+        for (int k = 0; k < 4; ++k) for (int n = 0; n < 16; ++n) b[k * 16 + n] = (float)((3 * k + n) % 5 - 2);
+        for (int m = 0; m < 16; ++m) for (int k = 0; k < 16; ++k) a2[m * 16 + k] = (float)((2 * m + 3 * k) % 4 - 1);
+        for (int m = 0; m < 16; ++m) for (int n = 0; n < 16; ++n) { float t = 0; for (int k = 0; k < 4; ++k) t += a[m * 4 + k] * b[k * 16 + n]; x[m * 16 + n] = t; }
+        for (int m = 0; m < 16; ++m) for (int n = 0; n < 16; ++n) { float t = 0; for (int k = 0; k < 16; ++k) t += a2[m * 16 + k] * x[k * 16 + n]; y[m * 16 + n] = t; }
+        float *da, *db, *da2, *d1, *d2;
+        CK(hipMalloc(&da, 256)); CK(hipMalloc(&db, 256)); CK(hipMalloc(&da2, 1024)); CK(hipMalloc(&d1, 1024)); CK(hipMalloc(&d2, 1024));
+        CK(hipMemcpy(da, a.data(), 256, hipMemcpyHostToDevice)); CK(hipMemcpy(db, b.data(), 256, hipMemcpyHostToDevice));
+        CK(hipMemcpy(da2, a2.data(), 1024, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_mfma64, 1, 64, 0, 0, da, db, d1, d2); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(got.data(), d1, 1024, hipMemcpyDeviceToHost)); CK(hipMemcpy(got2.data(), d2, 1024, hipMemcpyDeviceToHost));
+        int bad = 0, bad2 = 0; for (int i = 0; i < 256; ++i) { bad += got[i] != x[i]; bad2 += got2[i] != x[i]; }
+        printf("5. mfma_f64_16x16x4 / mfma_f32_16x16x4 lane maps: %s (%d / %d mismatches)\n", (bad || bad2) ? "FAIL" : "PASS", bad, bad2); fails += (bad || bad2) != 0;
+        hipLaunchKernelGGL(k_chain64, 1, 64, 0, 0, da, db, da2, d1); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(got.data(), d1, 1024, hipMemcpyDeviceToHost));
+        bad = 0; for (int i = 0; i < 256; ++i) bad += got[i] != y[i];
+        printf("6. f64 accumulator as B operand of the f32 MFMA (keys 4r..4r+3 per step): %s (%d mismatches)\n", bad ? "FAIL" : "PASS", bad); fails += bad != 0;
     }
     printf("%s\n", fails ? "PROBE: FAILURES" : "PROBE: ALL PASS");
     return fails ? 1 : 0;
