@@ -18,6 +18,10 @@ collective on the timed path.  Rank 0 prints ONE JSON line:
                    against 8 TB/s HBM peak (rank 0, N=1 only)
   cpu_config1      torch CPU timings of BASELINE config 1 (softmax 1024^2, naive attention
                    N=128 d=64), for reference beside the GPU numbers
+  attention_f32    the float32 path (float64-MFMA logits + float32-MFMA P.V): the reference's
+                   my_attention(Q, K_t, V) at N=128 d=64 (config 1) and N=1024 d=64 (its largest
+                   test shape), and the batched float32 flavour of the headline shape, against
+                   104.8 TFLOP/s = 4 / (2/78.6 + 2/157.3), the two matrix rates in series
   power_context    the same attention launch on all-ones operands, and the vendor bf16 GEMM
                    (torch.matmul -> hipBLASLt, 8192^3) on random and all-ones operands: the chip
                    lowers its clock under the power limit when operands are random, so these
@@ -141,6 +145,30 @@ def power_context(mfa, B, H, N, d, dtype, scale):
     return res
 
 
+F32_PEAK_TFLOPS = 4.0 / (2.0 / 78.6 + 2.0 / 157.3)   # f64 MFMA for Q.K^T and f32 MFMA for P.V, in series
+
+
+def bench_attention_f32(mfa):
+    res = []
+    torch.manual_seed(1)
+    for n, d in ((128, 64), (1024, 64)):
+        q, k, v = (torch.randn(n, d, device="cuda") for _ in range(3))
+        kt = k.t().contiguous()
+        ms = _median_ms(lambda: mfa.my_attention(q, kt, v), iters=30)
+        tf = 4.0 * n * n * d / ms / 1e9
+        res.append({"call": f"my_attention N={n} d={d}", "us": round(ms * 1e3, 2), "TFLOP/s": round(tf, 3),
+                    "frac_mfma_f64_f32_peak": round(tf / F32_PEAK_TFLOPS, 4)})
+    B, H, N, d = 4, 32, 4096, 128
+    q, k, v = (torch.randn(B, H, N, d, device="cuda") for _ in range(3))
+    ms = _median_ms(lambda: mfa.flash_attn_fwd(q, k, v, scale=d ** -0.5), iters=5, warm=2)
+    tf = attn_flops(B, H, N, d) / ms / 1e9
+    res.append({"call": f"flash_attn_fwd float32 B={B} H={H} N={N} d={d}", "us": round(ms * 1e3, 1), "TFLOP/s": round(tf, 2),
+                "frac_mfma_f64_f32_peak": round(tf / F32_PEAK_TFLOPS, 4)})
+    del q, k, v
+    torch.cuda.empty_cache()
+    return res
+
+
 def cpu_baseline(B, H, N, d, scale, budget_s=12.0):
     """C oracle, float32 arithmetic, OpenMP: heads of the same workload until ~budget_s."""
     import numpy as np
@@ -246,6 +274,7 @@ def main():
     result["verify"] = {"gathered_head_checksums": int(table.shape[0]), "gather_ms_untimed_path": round(gather_ms, 3)}
     if rank == 0 and world == 1 and not args.no_extras:
         result["power_context"] = power_context(mfa, B, H, N, d, dtype, scale)
+        result["attention_f32"] = bench_attention_f32(mfa)
         result["softmax_sweep"] = bench_softmax_sweep(mfa)
         result["cpu_baseline"] = cpu_baseline(B, H, N, d, scale)
         result["cpu_config1"] = cpu_config1()
