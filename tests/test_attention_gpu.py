@@ -114,7 +114,10 @@ def test_bhnd_lowp_vs_oracle(mfa, dtype, shape, scaled):
     assert _maxdiff(lse.cpu().numpy(), ref_cpu.attention_lse(qr, kr, scale=scale)) <= 1e-3
 
 
-@pytest.mark.parametrize("shape", [(1, 1, 64, 64), (2, 3, 130, 64), (1, 2, 77, 128), (2, 1, 300, 40), (1, 2, 33, 5)])
+# the last three make the launcher pick several query groups per workgroup (with one and
+# with two key shares) and the 256-column build
+@pytest.mark.parametrize("shape", [(1, 1, 64, 64), (2, 3, 130, 64), (1, 2, 77, 128), (2, 1, 300, 40), (1, 2, 33, 5),
+                                   (4, 16, 512, 64), (1, 64, 256, 64), (2, 8, 200, 192)])
 def test_bhnd_f32_vs_oracle(mfa, shape):
     B, H, N, d = shape
     torch.manual_seed(1)
