@@ -269,7 +269,11 @@ def main():
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                      "kernel": "attn_fwd_mfma_pp_kernel", "launch_ms_mean": round(mean_ms, 4),
-                     "launch_ms_median": round(med_ms, 4), "flops_per_launch": flops},
+                     "launch_ms_median": round(med_ms, 4), "flops_per_launch": flops,
+                     # not collected by this run (counters need rocprofv3): the committed PMC passes of the
+                     # headline shape, TCC_EA0_RDREQ x 128 B per launch against 0.38 GB of Q/K/V
+                     "traffic_profiled": {"hbm_read_bytes_per_launch": 4.03e8, "shape": "B4 H32 N4096 d128 bf16",
+                                          "source": "profiles/r01_attn_headline_pmc.txt"}},
     }
     result["verify"] = {"gathered_head_checksums": int(table.shape[0]), "gather_ms_untimed_path": round(gather_ms, 3)}
     if rank == 0 and world == 1 and not args.no_extras:
