@@ -57,15 +57,16 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def attn_flops(B, H, N, d):
-    return 4.0 * B * H * N * N * d
+def attn_flops(B, H, N, d, causal=False):
+    """Algorithmic flops; under the causal mask the visible half of the N x N products."""
+    return 4.0 * B * H * N * N * d * (0.5 if causal else 1.0)
 
 
-def bench_attention(mfa, B, H, N, d, dtype, steps, warmup, world, scale):
+def bench_attention(mfa, B, H, N, d, dtype, steps, warmup, world, scale, causal=False):
     torch.manual_seed(1 + int(os.environ.get("RANK", "0")))
     q, k, v = (torch.randn(B, H, N, d, dtype=dtype, device="cuda") for _ in range(3))
     for _ in range(warmup):
-        out = mfa.flash_attn_fwd(q, k, v, scale=scale)
+        out = mfa.flash_attn_fwd(q, k, v, scale=scale, causal=causal)
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     stops = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     torch.cuda.synchronize()
@@ -75,7 +76,7 @@ def bench_attention(mfa, B, H, N, d, dtype, steps, warmup, world, scale):
     t0 = time.perf_counter()
     for i in range(steps):
         starts[i].record()
-        out = mfa.flash_attn_fwd(q, k, v, scale=scale)
+        out = mfa.flash_attn_fwd(q, k, v, scale=scale, causal=causal)
         stops[i].record()
     torch.cuda.synchronize()
     if world > 1:
@@ -220,6 +221,7 @@ def main():
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--scale", default="rsqrt_d", choices=["rsqrt_d", "one"],
                     help="logit scale: d^-0.5 (usual) or 1.0 (the reference's unscaled semantics)")
+    ap.add_argument("--causal", action="store_true", help="causal mask (not the BASELINE metric; counts half the flops)")
     ap.add_argument("--no-extras", action="store_true", help="skip softmax sweep and CPU baselines")
     args = ap.parse_args()
 
@@ -236,7 +238,7 @@ def main():
 
     B, H, N, d, dtype = WORKLOADS[args.workload]
     scale = d ** -0.5 if args.scale == "rsqrt_d" else 1.0
-    wall, mean_ms, med_ms, (_, _, _, out) = bench_attention(mfa, B, H, N, d, dtype, args.steps, args.warmup, world, scale)
+    wall, mean_ms, med_ms, (_, _, _, out) = bench_attention(mfa, B, H, N, d, dtype, args.steps, args.warmup, world, scale, args.causal)
     # Verification only, outside the timed region: every rank's per-head output checksums are
     # gathered over RCCL (xGMI); all ranks must end up with the same, finite table.
     from my_flash_attn_cuda import sharding
@@ -246,7 +248,7 @@ def main():
     torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - tg) * 1e3
     assert bool(torch.isfinite(table).all()) and table.shape == (world * B * H, 2)
-    flops = attn_flops(B, H, N, d)
+    flops = attn_flops(B, H, N, d, args.causal)
     value = world * args.steps * flops / wall / 1e12
     achieved = flops / (mean_ms * 1e-3) / 1e12
 
@@ -264,7 +266,7 @@ def main():
         "dtype": {torch.bfloat16: "bf16", torch.float16: "f16"}[dtype],
         "data": "synthetic (torch.randn, seed 1 + rank), resident in HBM before timing",
         "config": {"workload": f"attention forward {args.workload}: B={B} H={H} N={N} d={d} per GPU, "
-                               f"non-causal, scale={'d^-0.5' if args.scale == 'rsqrt_d' else '1.0'}",
+                               f"{'causal' if args.causal else 'non-causal'}, scale={'d^-0.5' if args.scale == 'rsqrt_d' else '1.0'}",
                    "B": B, "H": H, "N": N, "d": d, "sharding": f"batch x heads, {world} rank(s), no collective"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
@@ -276,7 +278,7 @@ def main():
                                           "source": "profiles/r01_attn_headline_pmc.txt"}},
     }
     result["verify"] = {"gathered_head_checksums": int(table.shape[0]), "gather_ms_untimed_path": round(gather_ms, 3)}
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and not args.causal:
         result["power_context"] = power_context(mfa, B, H, N, d, dtype, scale)
         result["attention_f32"] = bench_attention_f32(mfa)
         result["softmax_sweep"] = bench_softmax_sweep(mfa)

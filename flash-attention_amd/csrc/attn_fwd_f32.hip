@@ -54,7 +54,8 @@ template <int NB> constexpr int max_waves() { return NB <= 4 ? 16 : NB <= 8 ? 8 
 // NB: padded head dim / 16 (4, 8, 16 or 32).  KT: K is given transposed ([d, N], the reference's
 // my_attention layout) instead of [N, d].  VEC: d % 4 == 0 and all bases 16-byte aligned, so rows
 // are read and written as float4; otherwise element by element.
-template <int NB, bool KT, bool VEC>
+// CAUSAL: key j is visible to query i only if j <= i (batched entry point only).
+template <int NB, bool KT, bool VEC, bool CAUSAL = false>
 __global__ void __launch_bounds__(max_waves<NB>() * 64)
 attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
                     const float* __restrict__ Vg, float* __restrict__ Og, float* __restrict__ LSEg,
@@ -75,7 +76,9 @@ attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
 
     const int qrow = (blockIdx.x * QG + qg) * 16 + j;
     const int qrow_c = qrow < N ? qrow : N - 1;
-    const int ntiles = (N + 15) >> 4;
+    // causal: the wave's 16 rows see the key tiles up to their own (diagonal) tile, whose first
+    // key is visible to every one of them
+    const int ntiles = CAUSAL ? min((N + 15) >> 4, blockIdx.x * QG + qg + 1) : (N + 15) >> 4;
 
     // four consecutive floats of a row (zero past column d)
     auto row4 = [&](const float* row, int col) __attribute__((always_inline)) -> f32x4 {
@@ -106,6 +109,8 @@ attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
 #pragma unroll
     for (int b = 0; b < NB; ++b) qv[b] = row4(Qh + qrow_c * d, 16 * b + 4 * g);
 
+    auto visible = [&](int key) __attribute__((always_inline)) { return key < N && (!CAUSAL || key <= qrow); };
+
     f32x4 o[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) o[b] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -119,7 +124,7 @@ attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
 #pragma unroll
         for (int b = 0; b < NB; ++b) kf[b] = k4(key, 16 * b + 4 * g);
     };
-    if constexpr (PREFETCH) load_k(min(split, ntiles - 1));
+    if constexpr (PREFETCH) load_k(max(min(split, ntiles - 1), 0));
 
     for (int kt = split; kt < ntiles; kt += KS) {
         const int key0 = kt * 16;
@@ -172,7 +177,7 @@ attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             x[r] = c[r] * dscale;
-            if (key0 + 4 * r + g < N) tmax = fmaxf(tmax, (float)x[r]);
+            if (visible(key0 + 4 * r + g)) tmax = fmaxf(tmax, (float)x[r]);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
@@ -188,7 +193,7 @@ attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float e = (float)((x[r] - (double)m) * 1.4426950408889634);
-            p[r] = (key0 + 4 * r + g < N) ? __builtin_amdgcn_exp2f(e) : 0.f;
+            p[r] = visible(key0 + 4 * r + g) ? __builtin_amdgcn_exp2f(e) : 0.f;
             l += p[r];
         }
 
@@ -265,10 +270,10 @@ attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
     if (LSEg != nullptr && g == 0) LSEg[(long long)blockIdx.y * N + qrow] = m + logf(l);
 }
 
-template <int NB, bool KT, bool VEC>
+template <int NB, bool KT, bool VEC, bool CAUSAL = false>
 int launch(const float* q, const float* k, const float* v, float* o, float* lse,
            int64_t heads, int64_t N, int64_t d, float scale, hipStream_t s) {
-    auto kern = attn_fwd_f32_kernel<NB, KT, VEC>;
+    auto kern = attn_fwd_f32_kernel<NB, KT, VEC, CAUSAL>;
     constexpr int wmax = max_waves<NB>();
     const int64_t qgroups = cdiv(N, 16);
     const int64_t ntiles = cdiv(N, 16);
@@ -297,7 +302,12 @@ int launch(const float* q, const float* k, const float* v, float* o, float* lse,
 
 template <int NB>
 int launch_layout(const float* q, const float* k, const float* v, float* o, float* lse,
-                  int64_t heads, int64_t N, int64_t d, bool kt, bool vec, float scale, hipStream_t s) {
+                  int64_t heads, int64_t N, int64_t d, bool kt, bool vec, bool causal, float scale, hipStream_t s) {
+    if (causal) {
+        if (kt) return fail(MYFA_E_UNSUPPORTED, "attention (f32): the causal mask needs K as [N, d]");
+        return vec ? launch<NB, false, true, true>(q, k, v, o, lse, heads, N, d, scale, s)
+                   : launch<NB, false, false, true>(q, k, v, o, lse, heads, N, d, scale, s);
+    }
     if (kt) return vec ? launch<NB, true, true>(q, k, v, o, lse, heads, N, d, scale, s)
                        : launch<NB, true, false>(q, k, v, o, lse, heads, N, d, scale, s);
     return vec ? launch<NB, false, true>(q, k, v, o, lse, heads, N, d, scale, s)
@@ -311,7 +321,7 @@ int launch_layout(const float* q, const float* k, const float* v, float* o, floa
 //   K   layout [N, d] (batched entry point):          k_key_stride = d, k_d_stride = 1
 int attn_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse,
                  int64_t heads, int64_t N, int64_t d, int64_t k_key_stride, int64_t k_d_stride,
-                 float scale, hipStream_t s) {
+                 float scale, bool causal, hipStream_t s) {
     if (d > 512) return fail(MYFA_E_UNSUPPORTED, "attention (f32): head dim %lld > 512", (long long)d);
     if (N * d >= (1LL << 31) || heads > 65535)
         return fail(MYFA_E_UNSUPPORTED, "attention (f32): N*d=%lld per head or heads=%lld beyond the kernel's limits", (long long)(N * d), (long long)heads);
@@ -323,10 +333,10 @@ int attn_fwd_f32(const float* q, const float* k, const float* v, float* o, float
     const bool vec = d % 4 == 0 &&
         ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
           reinterpret_cast<uintptr_t>(o)) % 16 == 0);
-    if (d <= 64)  return launch_layout<4>(q, k, v, o, lse, heads, N, d, kt, vec, scale, s);
-    if (d <= 128) return launch_layout<8>(q, k, v, o, lse, heads, N, d, kt, vec, scale, s);
-    if (d <= 256) return launch_layout<16>(q, k, v, o, lse, heads, N, d, kt, vec, scale, s);
-    return launch_layout<32>(q, k, v, o, lse, heads, N, d, kt, vec, scale, s);
+    if (d <= 64)  return launch_layout<4>(q, k, v, o, lse, heads, N, d, kt, vec, causal, scale, s);
+    if (d <= 128) return launch_layout<8>(q, k, v, o, lse, heads, N, d, kt, vec, causal, scale, s);
+    if (d <= 256) return launch_layout<16>(q, k, v, o, lse, heads, N, d, kt, vec, causal, scale, s);
+    return launch_layout<32>(q, k, v, o, lse, heads, N, d, kt, vec, causal, scale, s);
 }
 
 }  // namespace myfa

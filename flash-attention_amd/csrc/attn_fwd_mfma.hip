@@ -344,7 +344,7 @@ template <int D> __device__ __forceinline__ constexpr int img_off(int row, int c
     return 16 * D * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
 }
 
-template <typename T, int D, bool STAMP = false>
+template <typename T, int D, bool STAMP = false, bool CAUSAL = false>
 __global__ void __launch_bounds__(kThreads, D == 64 ? 4 : 2)
 attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* __restrict__ Vg,
                         T* __restrict__ Og, float* __restrict__ LSEg, int N, int nqblk, int nwg,
@@ -368,7 +368,10 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
         lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
     }
     const int head = lid / nqblk;
-    const int q0 = (lid - head * nqblk) * kBQ;
+    // causal: a query block needs the key tiles up to its own last row only, so blocks differ
+    // in length; the long ones (high rows) of each head are started first
+    const int qblk = CAUSAL ? nqblk - 1 - (lid - head * nqblk) : lid - head * nqblk;
+    const int q0 = qblk * kBQ;
 
     unsigned long long t_kernel0 = 0, t_loop0 = 0, t_loop1 = 0;
     if constexpr (STAMP) t_kernel0 = stamp();
@@ -500,13 +503,15 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
     [[maybe_unused]] unsigned long long cyc_x1 = 0, cyc_x2 = 0;
     auto softmax = [&](int kv0) __attribute__((always_inline)) {
         unsigned long long s1 = 0, s2 = 0;
-        if (kv0 + kBKV > N) {
+        // keys past N, and under the causal mask keys after the lane's query row; a tile the
+        // wave's first row already covers entirely needs no look
+        if (kv0 + kBKV > N || (CAUSAL && kv0 + kBKV - 1 > q0 + 32 * wave_u)) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int key = kv0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (key >= N) s[kb][i] = -INFINITY;
+                    if (key >= N || (CAUSAL && key > qrow)) s[kb][i] = -INFINITY;
                 }
         }
         float tmax = s[0][0];
@@ -544,7 +549,9 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
                 for (int j = 0; j < 8; ++j) pb[2 * kb + st][j] = (T)s[kb][8 * st + j];
     };
 
-    const int T_ = (N + kBKV - 1) / kBKV;
+    // key tiles of this workgroup (causal: up to the block's last row; the first tile always
+    // holds key 0, which every row may see, so no row is ever fully masked there)
+    const int T_ = CAUSAL ? min((N + kBKV - 1) / kBKV, (q0 + kBQ) / kBKV) : (N + kBKV - 1) / kBKV;
 
     // Own LDS-DMA fetches have landed / phase boundary without draining the ones in flight.
     auto dma_wait = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
@@ -567,14 +574,14 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
     fetch_k(1, 1);
     const int qbyte = (wave_u < 2 ? 2 : wave_u < 4 ? 3 : wave_u < 6 ? 5 : 6) * TILE_B + (wave_u & 1) * (TILE_B / 2);
     {
-        const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc((void*)(Qg + hoff), 0, head_bytes, 0x00020000);
-        const int qrow0_b = (q0 + 32 * wave) * D * 2;      // in the lane offset: it is bounds-checked
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc((void*)(Qg + hoff), 0, head_bytes, 0x00020000);
+        [[maybe_unused]] const int qrow0_b = (q0 + 32 * wave) * D * 2;   // in the lane offset: it is bounds-checked
 #pragma unroll
         for (int pc = 0; pc < TILE_B / 2 / 1024; ++pc) {
             const int u = 64 * pc + lane;
             const int grp8 = u / (SUB_B / 16), within = u % (SUB_B / 16);
             const int row = 8 * grp8 + ((within & 31) >> 2);
-            const int ch = 4 * (within >> 5) + ((within & 3) ^ ((row >> 2) & 3));
+            [[maybe_unused]] const int ch = 4 * (within >> 5) + ((within & 3) ^ ((row >> 2) & 3));
 #if defined(__HIP_DEVICE_COMPILE__)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (lds_void*)(lds + qbyte + 1024 * pc), 16,
                                                      qrow0_b + (row * D + ch * 8) * 2, 0, 0, 0);
@@ -719,13 +726,13 @@ Tuning tuning() {
 
 template <typename T, int D>
 int launch(const void* q, const void* k, const void* v, void* o, float* lse,
-           int64_t heads, int64_t N, float scale, hipStream_t s) {
+           int64_t heads, int64_t N, float scale, bool causal, hipStream_t s) {
     const int64_t nqblk = cdiv(N, kBQ);
     const int64_t nwg = heads * nqblk;
     if (nwg > 0x7fffffffLL) return fail(MYFA_E_UNSUPPORTED, "attention: too many workgroups (%lld)", (long long)nwg);
     const float sl2 = scale * 1.4426950408889634f;
     const Tuning tn = tuning();
-    if (tn.variant == 0)
+    if (tn.variant == 0 && !causal)
         hipLaunchKernelGGL((attn_fwd_mfma_kernel<T, D>), dim3((unsigned)nwg), dim3(kThreads), 0, s,
                            static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
                            static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2);
@@ -735,7 +742,8 @@ int launch(const void* q, const void* k, const void* v, void* o, float* lse,
                                static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
                                static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, tn.thr, tn.dbg);
         };
-        if (tn.dbg != nullptr) go(attn_fwd_mfma_pp_kernel<T, D, true>);
+        if (causal) go(attn_fwd_mfma_pp_kernel<T, D, false, true>);
+        else if (tn.dbg != nullptr) go(attn_fwd_mfma_pp_kernel<T, D, true>);
         else go(attn_fwd_mfma_pp_kernel<T, D, false>);
     }
     return check_launch("attn_fwd_mfma");
@@ -745,13 +753,13 @@ int launch(const void* q, const void* k, const void* v, void* o, float* lse,
 
 // dtype: MYFA_F16 or MYFA_BF16; d: 64 or 128; heads = B*H
 int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* lse,
-                  int64_t heads, int64_t N, int64_t d, float scale, int dtype, hipStream_t s) {
+                  int64_t heads, int64_t N, int64_t d, float scale, int dtype, bool causal, hipStream_t s) {
     if (!(scale > 0.f)) return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16): scale must be > 0, got %g", (double)scale);
     if (N > 0x7fffffffLL / 256) return fail(MYFA_E_UNSUPPORTED, "attention: N=%lld too large", (long long)N);
-    if (dtype == MYFA_BF16 && d == 128) return launch<__bf16, 128>(q, k, v, o, lse, heads, N, scale, s);
-    if (dtype == MYFA_BF16 && d == 64)  return launch<__bf16, 64>(q, k, v, o, lse, heads, N, scale, s);
-    if (dtype == MYFA_F16 && d == 128)  return launch<_Float16, 128>(q, k, v, o, lse, heads, N, scale, s);
-    if (dtype == MYFA_F16 && d == 64)   return launch<_Float16, 64>(q, k, v, o, lse, heads, N, scale, s);
+    if (dtype == MYFA_BF16 && d == 128) return launch<__bf16, 128>(q, k, v, o, lse, heads, N, scale, causal, s);
+    if (dtype == MYFA_BF16 && d == 64)  return launch<__bf16, 64>(q, k, v, o, lse, heads, N, scale, causal, s);
+    if (dtype == MYFA_F16 && d == 128)  return launch<_Float16, 128>(q, k, v, o, lse, heads, N, scale, causal, s);
+    if (dtype == MYFA_F16 && d == 64)   return launch<_Float16, 64>(q, k, v, o, lse, heads, N, scale, causal, s);
     return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16): head dim %lld not in {64, 128}", (long long)d);
 }
 

@@ -32,9 +32,9 @@ int check_launch(const char* what) {
 int softmax_f32(const float* in, float* out, int64_t h, int64_t w, hipStream_t s);
 int attn_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse,
                  int64_t heads, int64_t N, int64_t d, int64_t k_key_stride, int64_t k_d_stride,
-                 float scale, hipStream_t s);
+                 float scale, bool causal, hipStream_t s);
 int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* lse,
-                  int64_t heads, int64_t N, int64_t d, float scale, int dtype, hipStream_t s);
+                  int64_t heads, int64_t N, int64_t d, float scale, int dtype, bool causal, hipStream_t s);
 
 }  // namespace myfa
 
@@ -70,11 +70,18 @@ int myfa_attn_fwd_f32(const float* q, const float* k_t, const float* v, float* o
     if (n == 0 || d == 0) return MYFA_OK;
     if (!q || !k_t || !v || !o) return fail(MYFA_E_INVALID, "attention: null pointer");
     // K_t is [d, n]: key stride 1, dim stride n
-    return attn_fwd_f32(q, k_t, v, o, nullptr, 1, n, d, 1, n, scale, static_cast<hipStream_t>(stream));
+    return attn_fwd_f32(q, k_t, v, o, nullptr, 1, n, d, 1, n, scale, false, static_cast<hipStream_t>(stream));
 }
 
 int myfa_attn_fwd_bhnd(const void* q, const void* k, const void* v, void* o, float* lse,
                        int64_t B, int64_t H, int64_t N, int64_t d, float scale, int dtype, void* stream) {
+    return myfa_attn_fwd_bhnd_ex(q, k, v, o, lse, B, H, N, d, scale, dtype, 0, stream);
+}
+
+int myfa_attn_fwd_bhnd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
+                          int64_t B, int64_t H, int64_t N, int64_t d, float scale, int dtype, int flags, void* stream) {
+    if ((flags & ~MYFA_ATTN_CAUSAL) != 0) return fail(MYFA_E_INVALID, "attention: unknown flag bits 0x%x", flags);
+    const bool causal = (flags & MYFA_ATTN_CAUSAL) != 0;
     if (B < 0 || H < 0 || N < 0 || d < 0)
         return fail(MYFA_E_INVALID, "attention: negative size B=%lld H=%lld N=%lld d=%lld",
                     (long long)B, (long long)H, (long long)N, (long long)d);
@@ -87,13 +94,13 @@ int myfa_attn_fwd_bhnd(const void* q, const void* k, const void* v, void* o, flo
             // K is [N, d]: key stride d, dim stride 1
             return attn_fwd_f32(static_cast<const float*>(q), static_cast<const float*>(k),
                                 static_cast<const float*>(v), static_cast<float*>(o), lse,
-                                heads, N, d, d, 1, scale, s);
+                                heads, N, d, d, 1, scale, causal, s);
         case MYFA_F16:
         case MYFA_BF16:
             if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) |
                  reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(o)) % 16 != 0)
                 return fail(MYFA_E_INVALID, "attention (f16/bf16): tensors must be 16-byte aligned");
-            return attn_fwd_mfma(q, k, v, o, lse, heads, N, d, scale, dtype, s);
+            return attn_fwd_mfma(q, k, v, o, lse, heads, N, d, scale, dtype, causal, s);
         default:
             return fail(MYFA_E_INVALID, "attention: unknown dtype tag %d", dtype);
     }

@@ -91,7 +91,10 @@ def my_attention(Q, K, V):
     return out
 
 
-def flash_attn_fwd(q, k, v, scale=1.0, return_lse=False):
+ATTN_CAUSAL = 1   # MYFA_ATTN_CAUSAL
+
+
+def flash_attn_fwd(q, k, v, scale=1.0, return_lse=False, causal=False):
     """Batched attention forward: softmax(scale * q @ k^T) @ v per (batch, head).
 
     q, k, v: contiguous (B, H, N, d) GPU tensors of one dtype (float16, bfloat16
@@ -101,6 +104,8 @@ def flash_attn_fwd(q, k, v, scale=1.0, return_lse=False):
     float16/bfloat16 run on the matrix cores and need d in {64, 128}.
     With return_lse=True also returns the float32 (B, H, N) row log-sum-exp of the
     scaled logits (the m + log l statistic of tests/test_flash_attn.py:58-59,98-99).
+    causal=True masks key j for query i when j > i, as
+    scaled_dot_product_attention(is_causal=True) does (the reference has no mask).
     """
     _check_input(q, "q"); _check_input(k, "k"); _check_input(v, "v")
     if q.dim() != 4:
@@ -115,10 +120,10 @@ def flash_attn_fwd(q, k, v, scale=1.0, return_lse=False):
     out = torch.empty_like(q)
     lse = torch.empty((B, H, N), dtype=torch.float32, device=q.device) if return_lse else None
     with torch.cuda.device(q.device):
-        _lib.check(_lib.lib.myfa_attn_fwd_bhnd(
+        _lib.check(_lib.lib.myfa_attn_fwd_bhnd_ex(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
             lse.data_ptr() if return_lse else None,
-            B, H, N, d, float(scale), _DTYPE_TAG[q.dtype], _stream()))
+            B, H, N, d, float(scale), _DTYPE_TAG[q.dtype], ATTN_CAUSAL if causal else 0, _stream()))
     return (out, lse) if return_lse else out
 
 

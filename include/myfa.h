@@ -104,6 +104,20 @@ int myfa_attn_fwd_bhnd(const void* q, const void* k, const void* v, void* o, flo
                        int64_t B, int64_t H, int64_t N, int64_t d,
                        float scale, int dtype, void* stream);
 
+/*
+ * The same with option bits.  MYFA_ATTN_CAUSAL: key j contributes to query i only
+ * if j <= i (the mask that autoregressive callers of a fused forward need; the
+ * reference has no masked variant -- its Python statement
+ * tests/test_flash_attn.py:46-101 and my_attention csrc/api.cpp:168-192 are both
+ * unmasked -- so this follows torch's scaled_dot_product_attention(is_causal=True),
+ * which is also what the oracle for it is pinned against).  flags = 0 is exactly
+ * myfa_attn_fwd_bhnd.  Unknown bits are an error.
+ */
+#define MYFA_ATTN_CAUSAL 1
+int myfa_attn_fwd_bhnd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
+                          int64_t B, int64_t H, int64_t N, int64_t d,
+                          float scale, int dtype, int flags, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

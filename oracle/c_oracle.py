@@ -37,6 +37,8 @@ def lib():
             f = getattr(L, name)
             f.argtypes = [fp, fp, fp, fp, i64, i64, i64, i64, ctypes.c_float]
             f.restype = None
+        L.oracle_attention_causal_f64acc.argtypes = [fp, fp, fp, fp, ctypes.POINTER(i64), i64, i64, i64, i64, ctypes.c_float]
+        L.oracle_attention_causal_f64acc.restype = None
         L.oracle_max_threads.restype = ctypes.c_int
         L.oracle_set_threads.argtypes = [ctypes.c_int]
         L.oracle_abi_version.restype = ctypes.c_int
@@ -60,10 +62,11 @@ def softmax_rows(x, f32_arith=False):
     return out
 
 
-def attention(q, k, v, scale=1.0, f32_arith=False):
+def attention(q, k, v, scale=1.0, f32_arith=False, causal_pos=None):
     """q: (..., Nq, d); k, v: (..., N, d) float32, k NOT transposed.  Returns float32 (..., Nq, d).
 
-    Nq may differ from N (a sample of query rows against all keys)."""
+    Nq may differ from N (a sample of query rows against all keys).  causal_pos: the Nq
+    sequence positions of the query rows; when given, row i sees keys 0..causal_pos[i]."""
     q, k, v = _f32c(q), _f32c(k), _f32c(v)
     assert k.shape == v.shape and q.ndim == k.ndim >= 2
     assert q.shape[:-2] == k.shape[:-2] and q.shape[-1] == k.shape[-1]
@@ -71,6 +74,14 @@ def attention(q, k, v, scale=1.0, f32_arith=False):
     n = k.shape[-2]
     heads = int(np.prod(q.shape[:-2], dtype=np.int64)) if q.ndim > 2 else 1
     out = np.empty_like(q)
+    if causal_pos is not None:
+        assert not f32_arith
+        pos = np.ascontiguousarray(np.asarray(causal_pos, dtype=np.int64))
+        assert pos.shape == (nq,)
+        lib().oracle_attention_causal_f64acc(_fp(q), _fp(k), _fp(v), _fp(out),
+                                             pos.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                             heads, nq, n, d, float(scale))
+        return out
     fn = lib().oracle_attention_f32 if f32_arith else lib().oracle_attention_f64acc
     fn(_fp(q), _fp(k), _fp(v), _fp(out), heads, nq, n, d, float(scale))
     return out

@@ -53,6 +53,10 @@ SOFTMAX_BOUND = 1e-6
 ATTN_BOUND = 5e-5   # the reference computes in float32; at N~1024 its own rounding error is ~1e-5
 
 
+# (B, H, N, d, scale) for the causal-mask fixtures
+CAUSAL_SHAPES = [(1, 2, 100, 64, 0.125), (2, 1, 257, 128, 1.0), (1, 1, 64, 40, 0.5)]
+
+
 def load_reference(ref_root):
     sys.dont_write_bytecode = True
     sys.modules.setdefault("my_flash_attn_cuda", types.ModuleType("my_flash_attn_cuda"))
@@ -148,6 +152,27 @@ def main():
         np.savez_compressed(os.path.join(args.out, name + ".npz"), q=qn, k=kn, v=vn,
                             out_ref_naive=o_naive, out_ref_flash=o_flash, out_sdpa=o_sdpa)
         manifest["attention"][name] = rec
+        print(name, rec)
+
+    # The causal mask has no counterpart in the reference: its oracles are pinned against
+    # PyTorch's own scaled_dot_product_attention(is_causal=True), in float64, and the fixtures
+    # hold that output.
+    manifest["attention_causal"] = {}
+    for (b, h, n, d, scale) in CAUSAL_SHAPES:
+        torch.manual_seed(1)
+        q, k, v = (torch.randn(b, h, n, d, dtype=torch.float32) for _ in range(3))
+        o_sdpa = torch.nn.functional.scaled_dot_product_attention(
+            q.double(), k.double(), v.double(), is_causal=True, scale=scale).numpy()
+        qn, kn, vn = q.numpy(), k.numpy(), v.numpy()
+        o_np = ref_cpu.attention_bhnd(qn, kn, vn, scale=scale, causal=True)
+        o_c = c_oracle.attention(qn, kn, vn, scale=scale, causal_pos=np.arange(n))
+        rec = {"oracle_np_vs_sdpa_f64": maxdiff(o_np, o_sdpa), "oracle_c_vs_sdpa_f64": maxdiff(o_c, o_sdpa),
+               "q_sha256": sha(qn)}
+        assert rec["oracle_np_vs_sdpa_f64"] <= 1e-12 and rec["oracle_c_vs_sdpa_f64"] <= 1e-6, rec
+        name = f"attn_causal_{b}x{h}x{n}x{d}"
+        np.savez_compressed(os.path.join(args.out, name + ".npz"), q=qn, k=kn, v=vn,
+                            out_sdpa_f64=o_sdpa.astype(np.float32), scale=np.float32(scale))
+        manifest["attention_causal"][name] = rec
         print(name, rec)
 
     with open(os.path.join(args.out, "MANIFEST.json"), "w") as f:

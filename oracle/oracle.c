@@ -79,15 +79,19 @@ void oracle_softmax_f32(const float* in, float* out, int64_t h, int64_t w) {
 /* -------------------------------------------------------------- attention */
 /* One (batch, head): q, k, v, o are (n, d) row-major; k is NOT transposed. */
 
+/* qpos (may be NULL): position of each query row in the sequence; when given, row i sees
+ * keys 0 .. qpos[i] only (the causal mask of scaled_dot_product_attention(is_causal=True);
+ * the reference itself has no masked variant). */
 static void attn_head_f64acc(const float* q, const float* k, const float* v, float* o,
-                             int64_t nq, int64_t n, int64_t d, double scale) {
+                             int64_t nq, int64_t n_all, int64_t d, double scale, const int64_t* qpos) {
 #pragma omp parallel
     {
-        double* s = (double*)malloc(sizeof(double) * (size_t)n);
+        double* s = (double*)malloc(sizeof(double) * (size_t)n_all);
         double* acc = (double*)malloc(sizeof(double) * (size_t)d);
 #pragma omp for schedule(static)
         for (int64_t i = 0; i < nq; ++i) {
             const float* qi = q + i * d;
+            const int64_t n = qpos ? (qpos[i] + 1 < n_all ? qpos[i] + 1 : n_all) : n_all;
             double mx = -INFINITY;
             for (int64_t j = 0; j < n; ++j) {
                 const float* kj = k + j * d;
@@ -154,7 +158,17 @@ void oracle_attention_f64acc(const float* q, const float* k, const float* v, flo
                              int64_t heads, int64_t nq, int64_t n, int64_t d, float scale) {
     for (int64_t h = 0; h < heads; ++h)
         attn_head_f64acc(q + h * nq * d, k + h * n * d, v + h * n * d, o + h * nq * d,
-                         nq, n, d, (double)scale);
+                         nq, n, d, (double)scale, NULL);
+}
+
+/* The same under the causal mask; qpos[nq] are the sequence positions of the query rows
+ * (identical for every head). */
+void oracle_attention_causal_f64acc(const float* q, const float* k, const float* v, float* o,
+                                    const int64_t* qpos, int64_t heads, int64_t nq, int64_t n,
+                                    int64_t d, float scale) {
+    for (int64_t h = 0; h < heads; ++h)
+        attn_head_f64acc(q + h * nq * d, k + h * n * d, v + h * n * d, o + h * nq * d,
+                         nq, n, d, (double)scale, qpos);
 }
 
 void oracle_attention_f32(const float* q, const float* k, const float* v, float* o,

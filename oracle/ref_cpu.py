@@ -129,7 +129,15 @@ def attention_flash_fa2(q, k, v, scale=1.0, kv_block=64, dtype=np.float64):
     return acc / l[:, None]
 
 
-def attention_bhnd(q, k, v, scale=1.0, dtype=np.float64):
+def _causal_mask(s):
+    """-inf above the diagonal of the last two axes: key j is hidden from query i when j > i
+    (torch's scaled_dot_product_attention(is_causal=True); the reference has no mask)."""
+    n, m = s.shape[-2:]
+    s[..., np.triu(np.ones((n, m), dtype=bool), k=1)] = -np.inf
+    return s
+
+
+def attention_bhnd(q, k, v, scale=1.0, dtype=np.float64, causal=False):
     """Batched statement: O[b,h] = softmax(scale * Q[b,h] K[b,h]^T) V[b,h].
 
     q, k, v are (B, H, N, d) (or any leading dims).  Inputs are taken as given:
@@ -138,17 +146,21 @@ def attention_bhnd(q, k, v, scale=1.0, dtype=np.float64):
     """
     q, k, v = _as(q, dtype), _as(k, dtype), _as(v, dtype)
     s = np.einsum("...nd,...md->...nm", q, k) * dtype(scale)
+    if causal:
+        _causal_mask(s)
     s -= s.max(axis=-1, keepdims=True)
     np.exp(s, out=s)
     s /= s.sum(axis=-1, keepdims=True)
     return np.einsum("...nm,...md->...nd", s, v)
 
 
-def attention_lse(q, k, scale=1.0, dtype=np.float64):
+def attention_lse(q, k, scale=1.0, dtype=np.float64, causal=False):
     """Row log-sum-exp of scale * Q K^T (natural log), the statistic m + ln(l)
     that the reference's sketch keeps as two arrays
     (flash_attention.cu:37-39; test_flash_attn.py:58-59)."""
     q, k = _as(q, dtype), _as(k, dtype)
     s = np.einsum("...nd,...md->...nm", q, k) * dtype(scale)
+    if causal:
+        _causal_mask(s)
     mx = s.max(axis=-1)
     return mx + np.log(np.exp(s - mx[..., None]).sum(axis=-1))

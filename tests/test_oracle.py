@@ -67,6 +67,26 @@ def test_attention_oracles_vs_golden(n, d, c_oracle):
     assert np.abs((m + np.log(l)) - lse).max() < 1e-10
 
 
+@pytest.mark.parametrize("name", ["attn_causal_1x2x100x64", "attn_causal_2x1x257x128", "attn_causal_1x1x64x40"])
+def test_causal_oracles_vs_sdpa_golden(name, c_oracle):
+    """The causal mask has no counterpart in the reference; its oracles are pinned against the
+    stored float64 output of torch's scaled_dot_product_attention(is_causal=True)."""
+    g = load_golden(name)
+    q, k, v, scale = g["q"], g["k"], g["v"], float(g["scale"])
+    n = q.shape[-2]
+    out_np = ref_cpu.attention_bhnd(q, k, v, scale=scale, causal=True)
+    out_c = c_oracle.attention(q, k, v, scale=scale, causal_pos=np.arange(n))
+    assert np.abs(out_np - g["out_sdpa_f64"]).max() <= 1e-6      # (the fixture is stored as float32)
+    assert np.abs(out_c - g["out_sdpa_f64"]).max() <= 1e-6
+    rows = np.array([0, n // 2, n - 1])
+    out_s = c_oracle.attention(q[..., rows, :], k, v, scale=scale, causal_pos=rows)
+    assert np.abs(out_s - out_np[..., rows, :]).max() <= 1e-6
+    # row 0 sees key 0 only
+    assert np.abs(out_np[..., 0, :] - v[..., 0, :]).max() <= 1e-7
+    lse = ref_cpu.attention_lse(q, k, scale=scale, causal=True)
+    assert np.abs(lse[..., 0] - scale * np.einsum("...d,...d->...", q[..., 0, :].astype(np.float64), k[..., 0, :].astype(np.float64))).max() < 1e-12
+
+
 def test_flash_block_sizes_match_reference_formula():
     # Bc = ceil(64 KiB / 4d), Br = min(Bc, d)  (tests/test_flash_attn.py:53-55)
     assert ref_cpu.flash_block_sizes(64) == (64, 256)

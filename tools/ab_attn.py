@@ -33,17 +33,18 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--scale", type=float, default=None)
+    ap.add_argument("--causal", action="store_true", help="causal mask; TFLOP/s then count half the flops")
     a = ap.parse_args()
     B, H, N, d = map(int, a.shape.split(","))
     dt = {"bf16": torch.bfloat16, "f16": torch.float16}[a.dtype]
     scale = a.scale if a.scale is not None else d ** -0.5
     torch.manual_seed(1)
     q, k, v = (torch.randn(B, H, N, d, dtype=dt, device="cuda") for _ in range(3))
-    flops = 4.0 * B * H * N * N * d
+    flops = 4.0 * B * H * N * N * d * (0.5 if a.causal else 1.0)
     outs, times = {}, {s: [] for s in a.specs}
     for s in a.specs:
         set_env(s)
-        outs[s] = mfa.flash_attn_fwd(q, k, v, scale=scale).float()
+        outs[s] = mfa.flash_attn_fwd(q, k, v, scale=scale, causal=a.causal).float()
     torch.cuda.synchronize()
     for _ in range(a.rounds):
         for s in a.specs:
@@ -51,7 +52,7 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
-                mfa.flash_attn_fwd(q, k, v, scale=scale)
+                mfa.flash_attn_fwd(q, k, v, scale=scale, causal=a.causal)
             e1.record()
             torch.cuda.synchronize()
             times[s].append(e0.elapsed_time(e1) / a.iters)
