@@ -16,6 +16,8 @@ collective on the timed path.  Rank 0 prints ONE JSON line:
                    a bounded sample of the same workload (rank 0, N=1 only)
   softmax_sweep    row-softmax GB/s (algorithmic 8 B/element) at n x n, n = 4096..32768,
                    against 8 TB/s HBM peak (rank 0, N=1 only)
+  softmax_1024     my_softmax at 1024 x 1024 timed the way the reference's benchmark.py does, beside the
+                   reference's published T4 numbers (the only timings it publishes)
   cpu_config1      torch CPU timings of BASELINE config 1 (softmax 1024^2, naive attention
                    N=128 d=64), for reference beside the GPU numbers
   attention_f32    the float32 path (float64-MFMA logits + float32-MFMA P.V): the reference's
@@ -170,6 +172,26 @@ def bench_attention_f32(mfa):
     return res
 
 
+def bench_softmax_1024(mfa, calls=1000):
+    """The one timing the reference publishes (README.md:44-54, taken by benchmark.py:12-20):
+    1024 x 1024 float32, `calls` back-to-back my_softmax calls between two synchronisations, mean
+    microseconds per call including launch overhead and the output allocation."""
+    torch.manual_seed(1)
+    x = torch.randn(1024, 1024, dtype=torch.float32, device="cuda")
+    for _ in range(20):
+        mfa.my_softmax(x, 5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter_ns()
+    for _ in range(calls):
+        mfa.my_softmax(x, 5)
+    torch.cuda.synchronize()
+    us = (time.perf_counter_ns() - t0) / calls / 1e3
+    dev_us = _median_ms(lambda: mfa.my_softmax(x, 5), iters=50) * 1e3
+    return {"method": f"{calls} back-to-back calls between synchronisations (the reference's benchmark.py)",
+            "us_per_call": round(us, 2), "us_per_call_single_event_bracketed": round(dev_us, 2),
+            "reference_published_us": {"kernel_1": 110, "kernel_5": 71, "hardware": "NVIDIA T4"}}
+
+
 def cpu_baseline(B, H, N, d, scale, budget_s=12.0):
     """C oracle, float32 arithmetic, OpenMP: heads of the same workload until ~budget_s."""
     import numpy as np
@@ -282,6 +304,7 @@ def main():
         result["power_context"] = power_context(mfa, B, H, N, d, dtype, scale)
         result["attention_f32"] = bench_attention_f32(mfa)
         result["softmax_sweep"] = bench_softmax_sweep(mfa)
+        result["softmax_1024"] = bench_softmax_1024(mfa)
         result["cpu_baseline"] = cpu_baseline(B, H, N, d, scale)
         result["cpu_config1"] = cpu_config1()
     elif rank == 0:
