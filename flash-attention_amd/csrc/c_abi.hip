@@ -30,6 +30,7 @@ int check_launch(const char* what) {
 
 // implemented in the kernel translation units
 int softmax_f32(const float* in, float* out, int64_t h, int64_t w, hipStream_t s);
+int softmax_rows(const void* in, void* out, int64_t h, int64_t w, int dtype, hipStream_t s);
 int attn_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse,
                  int64_t heads, int64_t N, int64_t d, int64_t k_key_stride, int64_t k_d_stride,
                  float scale, bool causal, hipStream_t s);
@@ -62,6 +63,10 @@ int myfa_device_info(int device, int* cu_count, int* lds_bytes, int* wave_size, 
 
 int myfa_softmax_f32(const float* in, float* out, int64_t h, int64_t w, void* stream) {
     return softmax_f32(in, out, h, w, static_cast<hipStream_t>(stream));
+}
+
+int myfa_softmax(const void* in, void* out, int64_t h, int64_t w, int dtype, void* stream) {
+    return softmax_rows(in, out, h, w, dtype, static_cast<hipStream_t>(stream));
 }
 
 int myfa_attn_fwd_f32(const float* q, const float* k_t, const float* v, float* o,

@@ -12,8 +12,9 @@
 //                                 items of VW floats per thread (covers w <= 32768)
 //   softmax_rows_stream<VW>       longer rows: online (max, sum) pass, then a
 //                                 second pass that re-reads and writes (12 B/elt)
-// VW = 4 needs w % 4 == 0 (then every row base is 16-byte aligned given a 16-byte
-// aligned tensor base); otherwise VW = 1.
+// An item is 16 bytes: VW = 4 floats, or 8 halves / bfloat16s (the element type E is a
+// template parameter; arithmetic is float32 whatever E is).  That needs w % VW == 0 (then
+// every row base is 16-byte aligned given a 16-byte aligned tensor base); otherwise VW = 1.
 #include "myfa_common.h"
 
 #include <cstdio>
@@ -24,33 +25,36 @@ namespace {
 
 constexpr float kLog2e = 1.4426950408889634f;
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+// VW elements of E as one vector (16 bytes when VW > 1)
+template <typename E, int VW> struct Pack { typedef E type __attribute__((ext_vector_type(VW))); };
+template <typename E> struct Pack<E, 1> { typedef E type; };
+template <typename E> constexpr int vec_width() { return 16 / (int)sizeof(E); }
 
-template <int VW, bool NT = true>
-__device__ __forceinline__ void vload(float (&dst)[VW], const float* p) {
-    if constexpr (VW == 4 && !NT) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(p);
-        dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2]; dst[3] = t[3];
-    } else if constexpr (VW == 4) {
-        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-        dst[0] = t[0]; dst[1] = t[1]; dst[2] = t[2]; dst[3] = t[3];
+template <typename E, int VW, bool NT = true>
+__device__ __forceinline__ void vload(float (&dst)[VW], const E* p) {
+    using P = typename Pack<E, VW>::type;
+    if constexpr (VW == 1) {
+        dst[0] = (float)__builtin_nontemporal_load(p);
     } else {
-        dst[0] = __builtin_nontemporal_load(p);
+        P t;
+        if constexpr (NT) t = __builtin_nontemporal_load(reinterpret_cast<const P*>(p));
+        else t = *reinterpret_cast<const P*>(p);
+#pragma unroll
+        for (int c = 0; c < VW; ++c) dst[c] = (float)t[c];
     }
 }
 
-template <int VW, bool NT = true>
-__device__ __forceinline__ void vstore(float* p, const float (&src)[VW]) {
-    if constexpr (VW == 4 && !NT) {
-        f32x4 t;
-        t[0] = src[0]; t[1] = src[1]; t[2] = src[2]; t[3] = src[3];
-        *reinterpret_cast<f32x4*>(p) = t;
-    } else if constexpr (VW == 4) {
-        f32x4 t;
-        t[0] = src[0]; t[1] = src[1]; t[2] = src[2]; t[3] = src[3];
-        __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
+template <typename E, int VW, bool NT = true>
+__device__ __forceinline__ void vstore(E* p, const float (&src)[VW]) {
+    using P = typename Pack<E, VW>::type;
+    if constexpr (VW == 1) {
+        __builtin_nontemporal_store((E)src[0], p);
     } else {
-        __builtin_nontemporal_store(src[0], p);
+        P t;
+#pragma unroll
+        for (int c = 0; c < VW; ++c) t[c] = (E)src[c];
+        if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<P*>(p));
+        else *reinterpret_cast<P*>(p) = t;
     }
 }
 
@@ -71,9 +75,9 @@ __device__ __forceinline__ float rowgroup_reduce(float wave_val, float* slot, in
     }
 }
 
-template <int TPR, int V, int VW, int NTM = 3, int MAP = 0>
+template <typename E, int TPR, int V, int VW, int NTM = 3, int MAP = 0>
 __global__ void __launch_bounds__((TPR < 256 ? 256 : TPR))
-softmax_rows_reg(const float* __restrict__ in, float* __restrict__ out, int64_t h, int64_t w) {
+softmax_rows_reg(const E* __restrict__ in, E* __restrict__ out, int64_t h, int64_t w) {
     constexpr int BLOCK = TPR < 256 ? 256 : TPR;
     constexpr int RPB = BLOCK / TPR;   // rows per workgroup
     constexpr int NW = TPR / 64;       // waves per row
@@ -86,8 +90,8 @@ softmax_rows_reg(const float* __restrict__ in, float* __restrict__ out, int64_t 
     // so this exit is uniform over everything that meets at a barrier below.
     if (row >= h) return;
 
-    const float* src = in + row * w;
-    float* dst = out + row * w;
+    const E* src = in + row * w;
+    E* dst = out + row * w;
     float* slot = scratch + row_in_blk * NW;
     const int wave_in_row = t >> 6;
 
@@ -103,7 +107,7 @@ softmax_rows_reg(const float* __restrict__ in, float* __restrict__ out, int64_t 
     for (int v = 0; v < V; ++v) {
         const int64_t col = item(v) * VW;
         if (col < w) {
-            vload<VW, (NTM & 1) != 0>(x[v], src + col);
+            vload<E, VW, (NTM & 1) != 0>(x[v], src + col);
         } else {
 #pragma unroll
             for (int c = 0; c < VW; ++c) x[v][c] = -INFINITY;
@@ -132,33 +136,28 @@ softmax_rows_reg(const float* __restrict__ in, float* __restrict__ out, int64_t 
         if (col < w) {
 #pragma unroll
             for (int c = 0; c < VW; ++c) x[v][c] *= inv;
-            vstore<VW, (NTM & 2) != 0>(dst + col, x[v]);
+            vstore<E, VW, (NTM & 2) != 0>(dst + col, x[v]);
         }
     }
 }
 
 // Rows too long to hold in registers: one 1024-thread workgroup per row.
-template <int VW>
+template <typename E, int VW>
 __global__ void __launch_bounds__(1024)
-softmax_rows_stream(const float* __restrict__ in, float* __restrict__ out, int64_t h, int64_t w) {
+softmax_rows_stream(const E* __restrict__ in, E* __restrict__ out, int64_t h, int64_t w) {
     constexpr int T = 1024, NW = T / 64;
     __shared__ float scratch[NW];
     const int64_t row = blockIdx.x;
     if (row >= h) return;
-    const float* src = in + row * w;
-    float* dst = out + row * w;
+    const E* src = in + row * w;
+    E* dst = out + row * w;
     const int t = threadIdx.x, wave = t >> 6;
 
     // pass 1: per-thread online (max, sum of 2^((x - max) * log2e))
     float mx = -INFINITY, sum = 0.f;
     for (int64_t col = (int64_t)t * VW; col < w; col += (int64_t)T * VW) {
         float x[VW];
-        if constexpr (VW == 4) {
-            const f32x4 q = *reinterpret_cast<const f32x4*>(src + col);
-            x[0] = q[0]; x[1] = q[1]; x[2] = q[2]; x[3] = q[3];
-        } else {
-            x[0] = src[col];
-        }
+        vload<E, VW, false>(x, src + col);
         float cm = x[0];
 #pragma unroll
         for (int c = 1; c < VW; ++c) cm = fmaxf(cm, x[c]);
@@ -178,11 +177,11 @@ softmax_rows_stream(const float* __restrict__ in, float* __restrict__ out, int64
     // pass 2: the row was just read, so most of it is still in L2 / Infinity Cache
     for (int64_t col = (int64_t)t * VW; col < w; col += (int64_t)T * VW) {
         float x[VW];
-        vload<VW>(x, src + col);
+        vload<E, VW>(x, src + col);
 #pragma unroll
         for (int c = 0; c < VW; ++c)
             x[c] = __builtin_amdgcn_exp2f((x[c] - row_mx) * kLog2e) * inv;
-        vstore<VW>(dst + col, x);
+        vstore<E, VW>(dst + col, x);
     }
 }
 
@@ -192,25 +191,25 @@ softmax_rows_stream(const float* __restrict__ in, float* __restrict__ out, int64
 //   pad : unused dynamic LDS, only there to cap the workgroups per CU
 struct Shape { int tpr, v, map, nt; unsigned pad; };
 
-template <int TPR, int V, int VW>
-void launch_reg(const float* in, float* out, int64_t h, int64_t w, hipStream_t s, const Shape& sh) {
+template <typename E, int TPR, int V, int VW>
+void launch_reg(const E* in, E* out, int64_t h, int64_t w, hipStream_t s, const Shape& sh) {
     constexpr int BLOCK = TPR < 256 ? 256 : TPR;
     constexpr int RPB = BLOCK / TPR;
     const dim3 g((unsigned)cdiv(h, RPB)), b(BLOCK);
-    if constexpr (VW == 4) {
-        if (sh.map == 1 && sh.nt == 2) hipLaunchKernelGGL((softmax_rows_reg<TPR, V, VW, 2, 1>), g, b, sh.pad, s, in, out, h, w);
-        else if (sh.map == 1)          hipLaunchKernelGGL((softmax_rows_reg<TPR, V, VW, 3, 1>), g, b, sh.pad, s, in, out, h, w);
-        else if (sh.nt == 2)           hipLaunchKernelGGL((softmax_rows_reg<TPR, V, VW, 2, 0>), g, b, sh.pad, s, in, out, h, w);
-        else                           hipLaunchKernelGGL((softmax_rows_reg<TPR, V, VW, 3, 0>), g, b, sh.pad, s, in, out, h, w);
+    if constexpr (VW > 1) {
+        if (sh.map == 1 && sh.nt == 2) hipLaunchKernelGGL((softmax_rows_reg<E, TPR, V, VW, 2, 1>), g, b, sh.pad, s, in, out, h, w);
+        else if (sh.map == 1)          hipLaunchKernelGGL((softmax_rows_reg<E, TPR, V, VW, 3, 1>), g, b, sh.pad, s, in, out, h, w);
+        else if (sh.nt == 2)           hipLaunchKernelGGL((softmax_rows_reg<E, TPR, V, VW, 2, 0>), g, b, sh.pad, s, in, out, h, w);
+        else                           hipLaunchKernelGGL((softmax_rows_reg<E, TPR, V, VW, 3, 0>), g, b, sh.pad, s, in, out, h, w);
     } else {
-        hipLaunchKernelGGL((softmax_rows_reg<TPR, V, VW, 3, 0>), g, b, sh.pad, s, in, out, h, w);
+        hipLaunchKernelGGL((softmax_rows_reg<E, TPR, V, VW, 3, 0>), g, b, sh.pad, s, in, out, h, w);
     }
 }
 
-template <int VW>
-bool dispatch_reg(const float* in, float* out, int64_t h, int64_t w, hipStream_t s, const Shape& sh) {
+template <typename E, int VW>
+bool dispatch_reg(const E* in, E* out, int64_t h, int64_t w, hipStream_t s, const Shape& sh) {
 #define MYFA_CASE(T, VV) \
-    if (sh.tpr == T && sh.v == VV) { launch_reg<T, VV, VW>(in, out, h, w, s, sh); return true; }
+    if (sh.tpr == T && sh.v == VV) { launch_reg<E, T, VV, VW>(in, out, h, w, s, sh); return true; }
     MYFA_CASE(64, 1) MYFA_CASE(64, 2) MYFA_CASE(64, 4) MYFA_CASE(64, 8)
     MYFA_CASE(256, 1) MYFA_CASE(256, 2) MYFA_CASE(256, 4) MYFA_CASE(256, 8)
     MYFA_CASE(512, 2) MYFA_CASE(512, 4) MYFA_CASE(512, 8)
@@ -227,8 +226,21 @@ bool dispatch_reg(const float* in, float* out, int64_t h, int64_t w, hipStream_t
 // workgroup's waves hold only padding; at 32768 unused LDS caps the workgroups per CU).
 // Tensors that fit the Infinity Cache are read with plain loads, larger ones streamed
 // with non-temporal loads; stores are always non-temporal.
-Shape choose_shape(int64_t items, int64_t tensor_bytes) {
+// 16-bit elements put 8 values (8 registers) in an item, so they take the shapes with half the
+// items per thread wherever the float32 choice would exceed 64 registers of row data.
+Shape choose_shape(int64_t items, int64_t tensor_bytes, int vw) {
     Shape sh{0, 0, 0, tensor_bytes <= (128LL << 20) ? 2 : 3, 0};
+    if (vw == 8) {
+        if (items <= 64)        { sh.tpr = 64;   sh.v = 1; }
+        else if (items <= 128)  { sh.tpr = 64;   sh.v = 2; }
+        else if (items <= 256)  { sh.tpr = 64;   sh.v = 4; }
+        else if (items <= 512)  { sh.tpr = 256;  sh.v = 2; }
+        else if (items <= 1024) { sh.tpr = 512;  sh.v = 2; sh.map = 1; }
+        else if (items <= 2048) { sh.tpr = 1024; sh.v = 2; sh.map = 1; }
+        else if (items <= 4096) { sh.tpr = 1024; sh.v = 4; sh.map = 1; }
+        else if (items <= 8192) { sh.tpr = 1024; sh.v = 8; sh.pad = 27000; }
+        return sh;
+    }
     if (items <= 64)        { sh.tpr = 64;   sh.v = 1; }
     else if (items <= 128)  { sh.tpr = 64;   sh.v = 2; }
     else if (items <= 256)  { sh.tpr = 64;   sh.v = 4; }
@@ -240,17 +252,17 @@ Shape choose_shape(int64_t items, int64_t tensor_bytes) {
     return sh;
 }
 
-}  // namespace
-
-int softmax_f32(const float* in, float* out, int64_t h, int64_t w, hipStream_t s) {
+template <typename E>
+int softmax_any(const E* in, E* out, int64_t h, int64_t w, hipStream_t s) {
     if (h < 0 || w < 0) return fail(MYFA_E_INVALID, "softmax: negative size h=%lld w=%lld", (long long)h, (long long)w);
     if (h == 0 || w == 0) return MYFA_OK;
     if (!in || !out) return fail(MYFA_E_INVALID, "softmax: null pointer");
     if (h > 0x7fffffffLL) return fail(MYFA_E_UNSUPPORTED, "softmax: h=%lld exceeds the grid limit", (long long)h);
-    const bool vec4 = (w % 4 == 0) && (reinterpret_cast<uintptr_t>(in) % 16 == 0) &&
-                      (reinterpret_cast<uintptr_t>(out) % 16 == 0);
-    const int vw = vec4 ? 4 : 1;
-    Shape sh = choose_shape(w / vw, h * w * 4);
+    constexpr int VWV = vec_width<E>();
+    const bool vec = (w % VWV == 0) && (reinterpret_cast<uintptr_t>(in) % 16 == 0) &&
+                     (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    const int vw = vec ? VWV : 1;
+    Shape sh = choose_shape(w / vw, h * w * (int64_t)sizeof(E), vw);
     // MYFA_SOFTMAX_SHAPE="tpr,v[,map[,nt[,pad]]]" overrides the choice (benchmark sweeps only).
     if (const char* e = std::getenv("MYFA_SOFTMAX_SHAPE")) {
         Shape o{0, 0, 0, 3, 0};
@@ -258,12 +270,28 @@ int softmax_f32(const float* in, float* out, int64_t h, int64_t w, hipStream_t s
         if (n >= 2 && (int64_t)o.tpr * o.v * vw >= w) sh = o;
     }
     bool done = false;
-    if (sh.tpr) done = vec4 ? dispatch_reg<4>(in, out, h, w, s, sh) : dispatch_reg<1>(in, out, h, w, s, sh);
+    if (sh.tpr) done = vec ? dispatch_reg<E, VWV>(in, out, h, w, s, sh) : dispatch_reg<E, 1>(in, out, h, w, s, sh);
     if (!done) {
-        if (vec4) hipLaunchKernelGGL(softmax_rows_stream<4>, dim3((unsigned)h), dim3(1024), 0, s, in, out, h, w);
-        else      hipLaunchKernelGGL(softmax_rows_stream<1>, dim3((unsigned)h), dim3(1024), 0, s, in, out, h, w);
+        if (vec) hipLaunchKernelGGL((softmax_rows_stream<E, VWV>), dim3((unsigned)h), dim3(1024), 0, s, in, out, h, w);
+        else     hipLaunchKernelGGL((softmax_rows_stream<E, 1>), dim3((unsigned)h), dim3(1024), 0, s, in, out, h, w);
     }
     return check_launch("softmax_rows");
+}
+
+}  // namespace
+
+int softmax_f32(const float* in, float* out, int64_t h, int64_t w, hipStream_t s) {
+    return softmax_any<float>(in, out, h, w, s);
+}
+
+// dtype: MYFA_F32, MYFA_F16 or MYFA_BF16 (element type of both tensors; arithmetic is float32)
+int softmax_rows(const void* in, void* out, int64_t h, int64_t w, int dtype, hipStream_t s) {
+    switch (dtype) {
+        case MYFA_F32:  return softmax_any<float>(static_cast<const float*>(in), static_cast<float*>(out), h, w, s);
+        case MYFA_F16:  return softmax_any<_Float16>(static_cast<const _Float16*>(in), static_cast<_Float16*>(out), h, w, s);
+        case MYFA_BF16: return softmax_any<__bf16>(static_cast<const __bf16*>(in), static_cast<__bf16*>(out), h, w, s);
+        default:        return fail(MYFA_E_INVALID, "softmax: unknown dtype tag %d", dtype);
+    }
 }
 
 }  // namespace myfa

@@ -70,6 +70,22 @@ def my_softmax(inp, kernel_no=1):
     return out
 
 
+def softmax_rows(inp):
+    """Row softmax of a 2-D float32, float16 or bfloat16 tensor; returns a new tensor of the
+    same dtype.  New surface (the reference's my_softmax is float32 only, csrc/api.cpp:116-118):
+    the arithmetic is float32 for every dtype, 16-bit rows only halve the bytes moved."""
+    _check_input(inp, "inp")
+    if inp.dtype not in _DTYPE_TAG:
+        raise RuntimeError(f"unsupported dtype {inp.dtype}")
+    if inp.dim() != 2:
+        raise RuntimeError(f"softmax_rows expects a 2-D tensor, got {inp.dim()}-D")
+    h, w = inp.shape
+    out = torch.empty_like(inp)
+    with torch.cuda.device(inp.device):
+        _lib.check(_lib.lib.myfa_softmax(inp.data_ptr(), out.data_ptr(), h, w, _DTYPE_TAG[inp.dtype], _stream()))
+    return out
+
+
 def my_attention(Q, K, V):
     """softmax(Q @ K) @ V for float32 Q:(n,d), K:(d,n) -- already transposed -- and V:(n,d).
 

@@ -71,6 +71,16 @@ int myfa_device_info(int device, int* cu_count, int* lds_bytes, int* wave_size,
 int myfa_softmax_f32(const float* in, float* out, int64_t h, int64_t w, void* stream);
 
 /*
+ * The same for float32, float16 or bfloat16 tensors (dtype: MYFA_F32 / MYFA_F16 /
+ * MYFA_BF16, the element type of both `in` and `out`); max, exponential and sum are
+ * float32 whatever the element type, the result is rounded once on the way out.
+ * The reference's my_softmax only takes float32 (csrc/api.cpp:116,118:
+ * data_ptr<float>()); 16-bit rows halve the bytes per element of this
+ * bandwidth-bound kernel.
+ */
+int myfa_softmax(const void* in, void* out, int64_t h, int64_t w, int dtype, void* stream);
+
+/*
  * 2-D single-head attention, float32, the reference's calling convention:
  *     o = softmax(scale * (q @ k_t)) @ v
  * q: [n, d]; k_t: [d, n] (K already transposed, as the reference's caller

@@ -127,3 +127,45 @@ def test_sweep_sizes_properties(mfa, c_oracle, n):
     # idempotence of the normalisation: softmax(log(out)) == out
     again = mfa.my_softmax(torch.log(out[rows].contiguous()), 1)
     assert float((again - out[rows]).abs().max()) <= ATOL
+
+
+# ---- float16 / bfloat16 rows (softmax_rows; the reference's my_softmax is float32 only) ----
+# Bound: the float32 result rounded once to the output type -- half an ulp of a value <= 1,
+# 2^-12 for float16 and 2^-9 for bfloat16 -- plus the float32 kernel's own 1e-5.
+LOWP_ATOL = {torch.float16: 2.0 ** -12 + 1e-5, torch.bfloat16: 2.0 ** -9 + 1e-5}
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("h,w", [(1, 1), (3, 7), (255, 516), (64, 8), (33, 1000), (16, 4096), (7, 8192),
+                                 (5, 16384), (3, 32768), (2, 65536), (2, 70001), (4, 12345)])
+def test_lowp_rows_vs_oracle(mfa, c_oracle, dtype, h, w):
+    torch.manual_seed(1)
+    x = (torch.randn(h, w) * 3).to(dtype)
+    out = mfa.softmax_rows(x.cuda())
+    assert out.dtype == dtype and out.shape == (h, w)
+    ref = c_oracle.softmax_rows(x.float().numpy())
+    o = out.float().cpu().numpy()
+    assert (o >= 0).all() and (o <= 1).all()
+    assert np.abs(o - ref).max() <= LOWP_ATOL[dtype]
+
+
+def test_lowp_matches_float32_kernel_on_the_same_values(mfa):
+    """Same arithmetic whatever the element type: the 16-bit result is the float32 result of the
+    widened input rounded once -- up to the order of the row sum, which follows the launch
+    shape (items are 16 bytes, so 8 halves against 4 floats), i.e. up to one ulp of the output."""
+    torch.manual_seed(2)
+    for dtype in (torch.float16, torch.bfloat16):
+        x = (torch.randn(37, 2048) * 2).to(dtype).cuda()
+        a = mfa.softmax_rows(x)
+        b = mfa.my_softmax(x.float(), 1).to(dtype)
+        assert float((a.float() - b.float()).abs().max()) <= 2 * LOWP_ATOL[dtype]
+        assert float((a != b).float().mean()) < 0.01
+    xf = torch.randn(9, 300, device="cuda")
+    assert torch.equal(mfa.softmax_rows(xf), mfa.my_softmax(xf, 1))
+
+
+def test_lowp_errors(mfa):
+    with pytest.raises(RuntimeError, match="unsupported dtype"):
+        mfa.softmax_rows(torch.zeros(2, 2, dtype=torch.float64, device="cuda"))
+    with pytest.raises(RuntimeError, match="2-D"):
+        mfa.softmax_rows(torch.zeros(2, 2, 2, dtype=torch.bfloat16, device="cuda"))
