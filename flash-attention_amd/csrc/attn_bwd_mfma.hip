@@ -1,0 +1,450 @@
+// Attention backward for f16 / bf16 on gfx950 matrix cores.
+//
+//     S = scale Q K^T,  P = exp(S - lse),  O = P V           (forward, lse saved per row)
+//     dV = P^T dO
+//     dP = dO V^T,  delta = rowsum(dO o O),  dS = P o (dP - delta)
+//     dQ = scale dS K,   dK = scale dS^T Q
+//
+// The reference has no backward at all (its forward kernel was never written,
+// csrc/my_flash_attn/flash_attention.cu:23-69, and setup.py:128 only hints at upstream's
+// DISABLE_BACKWARD switch); this is the natural continuation of the fused forward, in the
+// formulation of FlashAttention-2's backward with the row statistic m + log l saved by the
+// forward as one array (the l, m of tests/test_flash_attn.py:58-59,98-99).
+//
+// Three kernels, no atomics, deterministic:
+//   delta   one pass over dO and O.
+//   dQ      workgroup = 256 query rows (8 waves x 32), streams K/V tiles of 64 keys -- the
+//           forward kernel's arrangement: S^T = K Q^T and dP^T = V dO^T put the query on
+//           the lane, P and dS are formed per lane with the row's lse and delta as scalars,
+//           and dS^T (converted in place) is the B operand of dQ^T += K^T dS^T, K^T coming
+//           from the row-major K tile through the transposing LDS read.
+//   dK,dV   the mirror image: workgroup = 128 keys (4 waves x 32, one wave per SIMD so that
+//           K, V fragments and both accumulators fit its 512 registers), streams tiles of 64
+//           queries of Q and dO.  S = Q K^T and dP = dO V^T put the KEY on the lane;
+//           lse and delta vary along the accumulator's rows and come from LDS;
+//           dV^T += dO^T P and dK^T += Q^T dS take P and dS as B operands in place.
+// P is recomputed in each of the two kernels (7 tile products in all instead of 5 with
+// atomics on dQ).
+#include "attn_mfma_common.h"
+
+namespace myfa {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr int kTile = 64;            // rows of a streamed tile (keys in dQ, queries in dK/dV)
+
+// ---------------------------------------------------------------- delta = rowsum(dO o O)
+template <typename T, int D>
+__global__ void __launch_bounds__(256)
+attn_bwd_delta_kernel(const T* __restrict__ Og, const T* __restrict__ dOg, float* __restrict__ DELg, long long rows) {
+    using vec8 = typename Mma<T>::vec8;
+    constexpr int CPR = D / 8;                     // 16-byte chunks per row = threads per row
+    const long long row = (long long)blockIdx.x * (256 / CPR) + threadIdx.x / CPR;
+    const int ch = threadIdx.x % CPR;
+    float acc = 0.f;
+    if (row < rows) {
+        const vec8 a = *reinterpret_cast<const vec8*>(Og + row * D + ch * 8);
+        const vec8 b = *reinterpret_cast<const vec8*>(dOg + row * D + ch * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += (float)a[j] * (float)b[j];
+    }
+#pragma unroll
+    for (int m = 1; m < CPR; m <<= 1) acc += __shfl_xor(acc, m);
+    if (row < rows && ch == 0) DELg[row] = acc;
+}
+
+// ---------------------------------------------------------------- shared tile staging
+// A [kTile][D] tile goes global -> registers -> LDS in the image of attn_mfma_common.h; rows
+// past N repeat row N-1 (finite values; whatever they produce is masked).
+template <typename T, int D, int THREADS>
+struct TileStage {
+    static constexpr int CPR = D / 8;
+    static constexpr int LPT = kTile * CPR / THREADS;
+    u32x4 st[LPT];
+    __device__ __forceinline__ void load(const T* base, int row0, int N, int tid) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int id = tid + THREADS * i;
+            const int row = id / CPR, ch = id % CPR;
+            int g = row0 + row;
+            g = g < N ? g : N - 1;
+            st[i] = *reinterpret_cast<const u32x4*>(base + (size_t)g * D + ch * 8);
+        }
+    }
+    __device__ __forceinline__ void write(char* tile, int tid) const {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int id = tid + THREADS * i;
+            const int row = id / CPR, ch = id % CPR;
+            *reinterpret_cast<u32x4*>(tile + img_off<D>(row, ch)) = st[i];
+        }
+    }
+};
+
+// ---------------------------------------------------------------- dQ
+template <typename T, int D, bool CAUSAL>
+__global__ void __launch_bounds__(512, 2)
+attn_bwd_dq_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* __restrict__ Vg,
+                   const T* __restrict__ dOg, const float* __restrict__ LSEg, const float* __restrict__ DELg,
+                   T* __restrict__ dQg, int N, int nqblk, int nwg, float scale) {
+    using M = Mma<T>;
+    using vec8 = typename M::vec8;
+    using vec4 = typename M::vec4;
+    constexpr int THREADS = 512, BQ = 256;
+    constexpr int TILE_B = kTile * D * 2;
+    constexpr int KS = D / 16, DB = D / 32;
+
+    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_B];   // K0 K1 V0 V1
+
+    int lid;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, qq = nwg >> 3, rr = nwg & 7;
+        lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int head = lid / nqblk;
+    const int qblk = CAUSAL ? nqblk - 1 - (lid - head * nqblk) : lid - head * nqblk;   // causal: long blocks first
+    const int q0 = qblk * BQ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const size_t hoff = (size_t)head * (size_t)N * D;
+    const T* Kh = Kg + hoff;
+    const T* Vh = Vg + hoff;
+
+    const int qrow = q0 + wave * 32 + r;
+    const int qrow_c = qrow < N ? qrow : N - 1;
+    vec8 qf[KS], dof[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        qf[ks] = *reinterpret_cast<const vec8*>(Qg + hoff + (size_t)qrow_c * D + 16 * ks + 8 * h);
+        dof[ks] = *reinterpret_cast<const vec8*>(dOg + hoff + (size_t)qrow_c * D + 16 * ks + 8 * h);
+    }
+    const float lse2 = LSEg[(size_t)head * N + qrow_c] * kLog2e;
+    const float delta = DELg[(size_t)head * N + qrow_c];
+    const float sl2 = scale * kLog2e;
+
+    TileStage<T, D, THREADS> kst, vst;
+    f32x16 dq[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dq[db][i] = 0.f;
+
+    const int T_all = (N + kTile - 1) / kTile;
+    const int ntiles = CAUSAL ? min(T_all, (q0 + BQ) / kTile) : T_all;
+    kst.load(Kh, 0, N, tid);
+    vst.load(Vh, 0, N, tid);
+    kst.write(lds, tid);
+    vst.write(lds + 2 * TILE_B, tid);
+    __syncthreads();
+
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        const int kv0 = t * kTile;
+        // always issued (rows clamped inside): a load under a condition makes hipcc guard the
+        // staging registers with a full wait
+        kst.load(Kh, kv0 + kTile, N, tid);
+        vst.load(Vh, kv0 + kTile, N, tid);
+        const char* Kb = lds + buf * TILE_B;
+        const char* Vb = lds + (2 + buf) * TILE_B;
+
+        // ---- S^T = K Q^T and dP^T = V dO^T (key blocks x k-steps): query on the lane
+        f32x16 s[2], dp[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[kb][i] = 0.f; dp[kb][i] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const s16x8 a = *reinterpret_cast<const s16x8*>(Kb + img_off<D>(32 * kb + r, 2 * ks + h));
+                s[kb] = M::run(a, qf[ks], s[kb]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const s16x8 a = *reinterpret_cast<const s16x8*>(Vb + img_off<D>(32 * kb + r, 2 * ks + h));
+                dp[kb] = M::run(a, dof[ks], dp[kb]);
+            }
+        }
+
+        // ---- dS^T = P^T o (dP^T - delta), P recomputed from the saved row statistic
+        const bool edge = kv0 + kTile > N || (CAUSAL && kv0 + kTile - 1 > q0 + 32 * (wave));
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], sl2, -lse2));
+                if (edge) {
+                    const int key = kv0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= N || (CAUSAL && key > qrow)) p = 0.f;
+                }
+                s[kb][i] = p * (dp[kb][i] - delta);
+            }
+
+        // ---- dQ^T += K^T dS^T : 4 k-steps of 16 keys x DB row blocks
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                vec8 pb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[j] = (T)s[kb][8 * st + j];
+                const int r0 = 32 * kb + 16 * st + 4 * h + tq;
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const int ch = 4 * db + 2 * tg1 + (tp >> 1);
+                    const s16x4 lo = lds_read_tr(Kb + img_off<D>(r0, ch) + 8 * (tp & 1));
+                    const s16x4 hi = lds_read_tr(Kb + img_off<D>(r0 + 8, ch) + 8 * (tp & 1));
+                    s16x8 a;
+                    a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
+                    a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
+                    dq[db] = M::run(a, pb, dq[db]);
+                }
+            }
+
+        kst.write(lds + (buf ^ 1) * TILE_B, tid);
+        vst.write(lds + (2 + (buf ^ 1)) * TILE_B, tid);
+        __syncthreads();
+    }
+
+    if (qrow < N) {
+        T* row = dQg + hoff + (size_t)qrow * D;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                vec4 w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = (T)(dq[db][4 * g + j] * scale);
+                *reinterpret_cast<vec4*>(row + 32 * db + 8 * g + 4 * h) = w;
+            }
+    }
+}
+
+// ---------------------------------------------------------------- dK, dV
+template <typename T, int D, bool CAUSAL>
+__global__ void __launch_bounds__(256, 1)
+attn_bwd_dkv_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* __restrict__ Vg,
+                    const T* __restrict__ dOg, const float* __restrict__ LSEg, const float* __restrict__ DELg,
+                    T* __restrict__ dKg, T* __restrict__ dVg, int N, int nkblk, int nwg, float scale) {
+    using M = Mma<T>;
+    using vec8 = typename M::vec8;
+    using vec4 = typename M::vec4;
+    constexpr int THREADS = 256, BK = 128;
+    constexpr int TILE_B = kTile * D * 2;
+    constexpr int KS = D / 16, DB = D / 32;
+
+    // Q0 Q1 dO0 dO1, then lse*log2e and delta of the tile's 64 queries, double-buffered
+    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_B + 4 * kTile * 4];
+    float* stat = reinterpret_cast<float*>(lds + 4 * TILE_B);     // [buf][lse2 | delta][64]
+
+    int lid;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, qq = nwg >> 3, rr = nwg & 7;
+        lid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int head = lid / nkblk;
+    const int k0 = (lid - head * nkblk) * BK;      // causal: low key blocks see the most queries and come first
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const size_t hoff = (size_t)head * (size_t)N * D;
+    const T* Qh = Qg + hoff;
+    const T* dOh = dOg + hoff;
+    const float* lseh = LSEg + (size_t)head * N;
+    const float* delh = DELg + (size_t)head * N;
+
+    const int krow = k0 + wave * 32 + r;
+    const int krow_c = krow < N ? krow : N - 1;
+    vec8 kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = *reinterpret_cast<const vec8*>(Kg + hoff + (size_t)krow_c * D + 16 * ks + 8 * h);
+        vf[ks] = *reinterpret_cast<const vec8*>(Vg + hoff + (size_t)krow_c * D + 16 * ks + 8 * h);
+    }
+    const float sl2 = scale * kLog2e;
+
+    TileStage<T, D, THREADS> qst, dst;
+    float lse_st = 0.f, del_st = 0.f;
+    auto stage_load = [&](int q0) __attribute__((always_inline)) {
+        qst.load(Qh, q0, N, tid);
+        dst.load(dOh, q0, N, tid);
+        if (tid < kTile) {
+            const int g = min(q0 + tid, N - 1);
+            lse_st = lseh[g] * kLog2e;
+            del_st = delh[g];
+        }
+    };
+    auto stage_write = [&](int buf) __attribute__((always_inline)) {
+        qst.write(lds + buf * TILE_B, tid);
+        dst.write(lds + (2 + buf) * TILE_B, tid);
+        if (tid < kTile) {
+            stat[buf * 2 * kTile + tid] = lse_st;
+            stat[buf * 2 * kTile + kTile + tid] = del_st;
+        }
+    };
+
+    f32x16 dk[DB], dv[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dk[db][i] = 0.f; dv[db][i] = 0.f; }
+
+    const int T_all = (N + kTile - 1) / kTile;
+    const int t0 = CAUSAL ? k0 / kTile : 0;        // causal: queries before the block's first key see none of it
+    stage_load(t0 * kTile);
+    stage_write(0);
+    __syncthreads();
+
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
+
+    for (int t = t0; t < T_all; ++t) {
+        const int buf = (t - t0) & 1;
+        const int qt0 = t * kTile;
+        stage_load(qt0 + kTile);
+        const char* Qb = lds + buf * TILE_B;
+        const char* dOb = lds + (2 + buf) * TILE_B;
+        const float* lse2b = stat + buf * 2 * kTile;
+        const float* delb = lse2b + kTile;
+
+        // ---- S = Q K^T and dP = dO V^T (query blocks x k-steps): key on the lane
+        f32x16 s[2], dp[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[qb][i] = 0.f; dp[qb][i] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const s16x8 a = *reinterpret_cast<const s16x8*>(Qb + img_off<D>(32 * qb + r, 2 * ks + h));
+                s[qb] = M::run(a, kf[ks], s[qb]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const s16x8 a = *reinterpret_cast<const s16x8*>(dOb + img_off<D>(32 * qb + r, 2 * ks + h));
+                dp[qb] = M::run(a, vf[ks], dp[qb]);
+            }
+        }
+
+        // ---- P and dS; accumulator register i of block qb is query 32qb + (i&3) + 8(i>>2) + 4h
+        const bool edge = qt0 + kTile > N || k0 + BK > N || (CAUSAL && k0 + BK - 1 > qt0);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int qi = 32 * qb + 8 * g + 4 * h;
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse2b + qi);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(delb + qi);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 4 * g + j;
+                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][i], sl2, -l4[j]));
+                    if (edge) {
+                        const int qglob = qt0 + qi + j;
+                        if (qglob >= N || krow >= N || (CAUSAL && krow > qglob)) p = 0.f;
+                    }
+                    s[qb][i] = p;
+                    dp[qb][i] = p * (dp[qb][i] - d4[j]);
+                }
+            }
+
+        // ---- dV^T += dO^T P and dK^T += Q^T dS : 4 k-steps of 16 queries x DB row blocks
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                vec8 pb, sb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { pb[j] = (T)s[qb][8 * st + j]; sb[j] = (T)dp[qb][8 * st + j]; }
+                const int r0 = 32 * qb + 16 * st + 4 * h + tq;
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const int ch = 4 * db + 2 * tg1 + (tp >> 1);
+                    {
+                        const s16x4 lo = lds_read_tr(dOb + img_off<D>(r0, ch) + 8 * (tp & 1));
+                        const s16x4 hi = lds_read_tr(dOb + img_off<D>(r0 + 8, ch) + 8 * (tp & 1));
+                        s16x8 a;
+                        a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
+                        a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
+                        dv[db] = M::run(a, pb, dv[db]);
+                    }
+                    {
+                        const s16x4 lo = lds_read_tr(Qb + img_off<D>(r0, ch) + 8 * (tp & 1));
+                        const s16x4 hi = lds_read_tr(Qb + img_off<D>(r0 + 8, ch) + 8 * (tp & 1));
+                        s16x8 a;
+                        a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
+                        a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
+                        dk[db] = M::run(a, sb, dk[db]);
+                    }
+                }
+            }
+
+        stage_write(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (krow < N) {
+        T* krow_p = dKg + hoff + (size_t)krow * D;
+        T* vrow_p = dVg + hoff + (size_t)krow * D;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                vec4 wk, wv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { wk[j] = (T)(dk[db][4 * g + j] * scale); wv[j] = (T)dv[db][4 * g + j]; }
+                *reinterpret_cast<vec4*>(krow_p + 32 * db + 8 * g + 4 * h) = wk;
+                *reinterpret_cast<vec4*>(vrow_p + 32 * db + 8 * g + 4 * h) = wv;
+            }
+    }
+}
+
+template <typename T, int D>
+int launch_bwd(const void* q, const void* k, const void* v, const void* o, const float* lse, const void* dout,
+               void* dq, void* dk, void* dv, float* delta, int64_t heads, int64_t N, float scale,
+               bool causal, hipStream_t s) {
+    const T* Q = static_cast<const T*>(q);
+    const T* K = static_cast<const T*>(k);
+    const T* V = static_cast<const T*>(v);
+    const T* O = static_cast<const T*>(o);
+    const T* dO = static_cast<const T*>(dout);
+    const int64_t rows = heads * N;
+    constexpr int RPB = 256 / (D / 8);
+    hipLaunchKernelGGL((attn_bwd_delta_kernel<T, D>), dim3((unsigned)cdiv(rows, RPB)), dim3(256), 0, s, O, dO, delta, (long long)rows);
+
+    const int64_t nqblk = cdiv(N, 256), nkblk = cdiv(N, 128);
+    const int64_t nq = heads * nqblk, nk = heads * nkblk;
+    if (nq > 0x7fffffffLL || nk > 0x7fffffffLL) return fail(MYFA_E_UNSUPPORTED, "attention backward: too many workgroups");
+    if (causal) {
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, true>), dim3((unsigned)nk), dim3(256), 0, s, Q, K, V, dO, lse, delta,
+                           static_cast<T*>(dk), static_cast<T*>(dv), (int)N, (int)nkblk, (int)nk, scale);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, true>), dim3((unsigned)nq), dim3(512), 0, s, Q, K, V, dO, lse, delta,
+                           static_cast<T*>(dq), (int)N, (int)nqblk, (int)nq, scale);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, false>), dim3((unsigned)nk), dim3(256), 0, s, Q, K, V, dO, lse, delta,
+                           static_cast<T*>(dk), static_cast<T*>(dv), (int)N, (int)nkblk, (int)nk, scale);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, false>), dim3((unsigned)nq), dim3(512), 0, s, Q, K, V, dO, lse, delta,
+                           static_cast<T*>(dq), (int)N, (int)nqblk, (int)nq, scale);
+    }
+    return check_launch("attn_bwd_mfma");
+}
+
+}  // namespace
+
+// dtype: MYFA_F16 or MYFA_BF16; d: 64 or 128; heads = B*H.  `delta` is a caller-provided
+// float32 workspace of heads * N elements (the library allocates nothing).
+int attn_bwd_mfma(const void* q, const void* k, const void* v, const void* o, const float* lse, const void* dout,
+                  void* dq, void* dk, void* dv, float* delta, int64_t heads, int64_t N, int64_t d,
+                  float scale, int dtype, bool causal, hipStream_t s) {
+    if (!(scale > 0.f)) return fail(MYFA_E_UNSUPPORTED, "attention backward: scale must be > 0, got %g", (double)scale);
+    if (N > 0x7fffffffLL / 256) return fail(MYFA_E_UNSUPPORTED, "attention backward: N=%lld too large", (long long)N);
+    if (dtype == MYFA_BF16 && d == 128) return launch_bwd<__bf16, 128>(q, k, v, o, lse, dout, dq, dk, dv, delta, heads, N, scale, causal, s);
+    if (dtype == MYFA_BF16 && d == 64)  return launch_bwd<__bf16, 64>(q, k, v, o, lse, dout, dq, dk, dv, delta, heads, N, scale, causal, s);
+    if (dtype == MYFA_F16 && d == 128)  return launch_bwd<_Float16, 128>(q, k, v, o, lse, dout, dq, dk, dv, delta, heads, N, scale, causal, s);
+    if (dtype == MYFA_F16 && d == 64)   return launch_bwd<_Float16, 64>(q, k, v, o, lse, dout, dq, dk, dv, delta, heads, N, scale, causal, s);
+    return fail(MYFA_E_UNSUPPORTED, "attention backward: needs float16 or bfloat16 and head dim 64 or 128 (got dtype %d, d %lld)", dtype, (long long)d);
+}
+
+}  // namespace myfa

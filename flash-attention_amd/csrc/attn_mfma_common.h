@@ -1,0 +1,73 @@
+// Pieces shared by the f16/bf16 matrix-core attention kernels (forward and backward):
+// vector types, the MFMA wrapper per element type, the transposing LDS read, the
+// lane-half exchanges and the LDS tile image.
+#ifndef MYFA_ATTN_MFMA_COMMON_H_
+#define MYFA_ATTN_MFMA_COMMON_H_
+#include "myfa_common.h"
+
+namespace myfa {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mma;
+template <> struct Mma<__bf16> {
+    using vec8 = bf16x8;
+    using vec4 = bf16x4;
+    static __device__ __forceinline__ f32x16 run(s16x8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vec8, a), b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<_Float16> {
+    using vec8 = f16x8;
+    using vec4 = f16x4;
+    static __device__ __forceinline__ f32x16 run(s16x8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vec8, a), b, c, 0, 0, 0);
+    }
+};
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ s16x4 lds_read_tr(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+}
+
+// Both lane halves' values of x, in every lane: {x[lane & 31], x[(lane & 31) + 32]}.
+// v_permlane32_swap exchanges the upper half of its first operand with the lower
+// half of its second.  The two results are copied out of the builtin's vector
+// before any bit_cast: __builtin_bit_cast applied directly to an element of that
+// vector reads element 0 for every index (hipcc 7.2).
+struct HalfPair { float lo, hi; };
+__device__ __forceinline__ HalfPair both_halves(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned a = r[0], b = r[1];
+    return {__builtin_bit_cast(float, a), __builtin_bit_cast(float, b)};
+}
+__device__ __forceinline__ float half_exchange_max(float x) {
+    const HalfPair p = both_halves(x);
+    return fmaxf(p.lo, p.hi);
+}
+__device__ __forceinline__ float half_exchange_sum(float x) {
+    const HalfPair p = both_halves(x);
+    return p.lo + p.hi;
+}
+
+// LDS image of a [rows][D] 16-bit tile made of 8-row x 64-byte subtiles (c = 16-byte chunk of
+// the row).  Row reads (ds_read_b128: row = lane & 31, chunk 2*kstep + (lane >> 5)) and
+// transposing reads (ds_read_b64_tr_b16) are both bank-conflict-free on it.
+template <int D> __device__ __forceinline__ constexpr int img_off(int row, int ch) {
+    return 16 * D * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+}
+
+}  // namespace
+}  // namespace myfa
+#endif  // MYFA_ATTN_MFMA_COMMON_H_

@@ -36,6 +36,9 @@ int attn_fwd_f32(const float* q, const float* k, const float* v, float* o, float
                  float scale, bool causal, hipStream_t s);
 int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* lse,
                   int64_t heads, int64_t N, int64_t d, float scale, int dtype, bool causal, hipStream_t s);
+int attn_bwd_mfma(const void* q, const void* k, const void* v, const void* o, const float* lse, const void* dout,
+                  void* dq, void* dk, void* dv, float* delta, int64_t heads, int64_t N, int64_t d,
+                  float scale, int dtype, bool causal, hipStream_t s);
 
 }  // namespace myfa
 
@@ -109,6 +112,26 @@ int myfa_attn_fwd_bhnd_ex(const void* q, const void* k, const void* v, void* o, 
         default:
             return fail(MYFA_E_INVALID, "attention: unknown dtype tag %d", dtype);
     }
+}
+
+int myfa_attn_bwd_bhnd(const void* q, const void* k, const void* v, const void* o, const float* lse,
+                       const void* dout, void* dq, void* dk, void* dv, float* delta_ws,
+                       int64_t B, int64_t H, int64_t N, int64_t d, float scale, int dtype, int flags, void* stream) {
+    if (B < 0 || H < 0 || N < 0 || d < 0)
+        return fail(MYFA_E_INVALID, "attention backward: negative size B=%lld H=%lld N=%lld d=%lld",
+                    (long long)B, (long long)H, (long long)N, (long long)d);
+    if ((flags & ~MYFA_ATTN_CAUSAL) != 0) return fail(MYFA_E_INVALID, "attention backward: unknown flag bits 0x%x", flags);
+    if (B == 0 || H == 0 || N == 0 || d == 0) return MYFA_OK;
+    if (!q || !k || !v || !o || !lse || !dout || !dq || !dk || !dv || !delta_ws)
+        return fail(MYFA_E_INVALID, "attention backward: null pointer");
+    if (dtype != MYFA_F16 && dtype != MYFA_BF16)
+        return fail(MYFA_E_UNSUPPORTED, "attention backward: float16 or bfloat16 only (dtype tag %d)", dtype);
+    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
+         reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dq) |
+         reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv)) % 16 != 0)
+        return fail(MYFA_E_INVALID, "attention backward: tensors must be 16-byte aligned");
+    return attn_bwd_mfma(q, k, v, o, lse, dout, dq, dk, dv, delta_ws, B * H, N, d, scale, dtype,
+                         (flags & MYFA_ATTN_CAUSAL) != 0, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

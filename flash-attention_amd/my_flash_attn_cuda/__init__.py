@@ -143,6 +143,52 @@ def flash_attn_fwd(q, k, v, scale=1.0, return_lse=False, causal=False):
     return (out, lse) if return_lse else out
 
 
+def flash_attn_bwd(dout, q, k, v, out, lse, scale=1.0, causal=False):
+    """Gradients (dq, dk, dv) of flash_attn_fwd for float16 / bfloat16 (B, H, N, d) tensors,
+    d in {64, 128}.  `out` and `lse` are the forward's results (return_lse=True), `dout` the
+    gradient of `out`.  The reference has no backward; this is the derivative of the forward
+    it sketches (csrc/my_flash_attn/flash_attention.cu:23-69)."""
+    for t, name in ((dout, "dout"), (q, "q"), (k, "k"), (v, "v"), (out, "out"), (lse, "lse")):
+        _check_input(t, name)
+    if q.dim() != 4 or not (q.shape == k.shape == v.shape == out.shape == dout.shape):
+        raise RuntimeError("Wrong sizes!")
+    if not (q.dtype == k.dtype == v.dtype == out.dtype == dout.dtype):
+        raise RuntimeError("Scalar type mismatch!")
+    if q.dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError(f"flash_attn_bwd supports float16 and bfloat16, got {q.dtype}")
+    B, H, N, d = q.shape
+    if lse.dtype != torch.float32 or tuple(lse.shape) != (B, H, N):
+        raise RuntimeError("lse must be the float32 (B, H, N) tensor returned by flash_attn_fwd")
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty((B, H, N), dtype=torch.float32, device=q.device)   # workspace: rowsum(dout * out)
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.lib.myfa_attn_bwd_bhnd(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr(),
+            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(),
+            B, H, N, d, float(scale), _DTYPE_TAG[q.dtype], ATTN_CAUSAL if causal else 0, _stream()))
+    return dq, dk, dv
+
+
+class _FlashAttnFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, scale, causal):
+        out, lse = flash_attn_fwd(q, k, v, scale=scale, return_lse=True, causal=causal)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.scale, ctx.causal = scale, causal
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        dq, dk, dv = flash_attn_bwd(dout.contiguous(), q, k, v, out, lse, scale=ctx.scale, causal=ctx.causal)
+        return dq, dk, dv, None, None
+
+
+def flash_attn_func(q, k, v, scale=1.0, causal=False):
+    """flash_attn_fwd with autograd support (float16 / bfloat16, d in {64, 128})."""
+    return _FlashAttnFunc.apply(q, k, v, scale, causal)
+
+
 # ---- the matmul trio ---------------------------------------------------------
 # Not on the softmax/attention path.  The reference's 16x16-tile kernel
 # (csrc/my_flash_attn/matmul.cu:22-50) and its cuBLAS wrapper (csrc/api.cpp:68-105)

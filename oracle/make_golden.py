@@ -57,6 +57,10 @@ ATTN_BOUND = 5e-5   # the reference computes in float32; at N~1024 its own round
 CAUSAL_SHAPES = [(1, 2, 100, 64, 0.125), (2, 1, 257, 128, 1.0), (1, 1, 64, 40, 0.5)]
 
 
+# (B, H, N, d, scale, causal) for the backward fixtures
+BWD_SHAPES = [(1, 2, 100, 64, 0.125, False), (1, 2, 129, 128, 128 ** -0.5, True), (2, 1, 64, 64, 1.0, True)]
+
+
 def load_reference(ref_root):
     sys.dont_write_bytecode = True
     sys.modules.setdefault("my_flash_attn_cuda", types.ModuleType("my_flash_attn_cuda"))
@@ -173,6 +177,27 @@ def main():
         np.savez_compressed(os.path.join(args.out, name + ".npz"), q=qn, k=kn, v=vn,
                             out_sdpa_f64=o_sdpa.astype(np.float32), scale=np.float32(scale))
         manifest["attention_causal"][name] = rec
+        print(name, rec)
+
+    # The backward has no counterpart in the reference either: its oracle is pinned against
+    # autograd of PyTorch's scaled_dot_product_attention in float64.
+    manifest["attention_bwd"] = {}
+    for (b, h, n, d, scale, causal) in BWD_SHAPES:
+        torch.manual_seed(1)
+        q, k, v, do = (torch.randn(b, h, n, d, dtype=torch.float32) for _ in range(4))
+        qd, kd, vd = (x.double().requires_grad_(True) for x in (q, k, v))
+        o = torch.nn.functional.scaled_dot_product_attention(qd, kd, vd, is_causal=causal, scale=scale)
+        o.backward(do.double())
+        ref = [x.grad.numpy() for x in (qd, kd, vd)]
+        got = ref_cpu.attention_bwd_bhnd(q.numpy(), k.numpy(), v.numpy(), do.numpy(), scale=scale, causal=causal)
+        rec = {f"oracle_{nm}_vs_autograd_f64": maxdiff(g, r) for nm, g, r in zip(("dq", "dk", "dv"), got, ref)}
+        assert max(rec.values()) <= 1e-10, rec
+        rec["q_sha256"] = sha(q.numpy())
+        name = f"attn_bwd_{b}x{h}x{n}x{d}" + ("_causal" if causal else "")
+        np.savez_compressed(os.path.join(args.out, name + ".npz"), q=q.numpy(), k=k.numpy(), v=v.numpy(), dout=do.numpy(),
+                            dq=ref[0].astype(np.float32), dk=ref[1].astype(np.float32), dv=ref[2].astype(np.float32),
+                            scale=np.float32(scale), causal=np.bool_(causal))
+        manifest["attention_bwd"][name] = rec
         print(name, rec)
 
     with open(os.path.join(args.out, "MANIFEST.json"), "w") as f:

@@ -164,3 +164,30 @@ def attention_lse(q, k, scale=1.0, dtype=np.float64, causal=False):
         _causal_mask(s)
     mx = s.max(axis=-1)
     return mx + np.log(np.exp(s - mx[..., None]).sum(axis=-1))
+
+
+def attention_bwd_bhnd(q, k, v, dout, scale=1.0, dtype=np.float64, causal=False):
+    """Gradients (dq, dk, dv) of attention_bhnd with respect to its inputs for an upstream
+    gradient `dout` of the output.  The reference has no backward (its fused forward is a
+    stub, csrc/my_flash_attn/flash_attention.cu:23-69); this is the derivative of the forward
+    statement above, pinned in oracle/make_golden.py against autograd of PyTorch's
+    scaled_dot_product_attention in float64.
+
+        P = softmax(scale Q K^T),  dV = P^T dO,  dP = dO V^T,
+        dS = P o (dP - rowsum(dO o O)),  dQ = scale dS K,  dK = scale dS^T Q
+    """
+    q, k, v, dout = _as(q, dtype), _as(k, dtype), _as(v, dtype), _as(dout, dtype)
+    s = np.einsum("...nd,...md->...nm", q, k) * dtype(scale)
+    if causal:
+        _causal_mask(s)
+    s -= s.max(axis=-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(axis=-1, keepdims=True)
+    o = np.einsum("...nm,...md->...nd", p, v)
+    dv = np.einsum("...nm,...nd->...md", p, dout)
+    dp = np.einsum("...nd,...md->...nm", dout, v)
+    delta = (dout * o).sum(axis=-1, keepdims=True)
+    ds = p * (dp - delta)
+    dq = np.einsum("...nm,...md->...nd", ds, k) * dtype(scale)
+    dk = np.einsum("...nm,...nd->...md", ds, q) * dtype(scale)
+    return dq, dk, dv

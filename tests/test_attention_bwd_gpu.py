@@ -1,0 +1,142 @@
+"""GPU parity tests for the attention backward (C ABI myfa_attn_bwd_bhnd, Python
+flash_attn_bwd / flash_attn_func).
+
+The reference has no backward (its fused forward is a stub,
+csrc/my_flash_attn/flash_attention.cu:23-69).  The oracle `ref_cpu.attention_bwd_bhnd` is
+pinned by oracle/make_golden.py against autograd of PyTorch's scaled_dot_product_attention in
+float64 (to 1e-13), and the fixtures tests/golden/attn_bwd_*.npz hold those autograd results.
+
+Tolerance.  Gradients are not O(1) like the forward's outputs, so the bound is relative to
+each gradient tensor's own largest entry: max|g - oracle| <= 2e-2 * max|oracle| for bfloat16
+and float16 alike (the forward's 2e-2, which for its O(1) outputs is the same statement),
+with the oracle evaluated on the rounded inputs.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import ref_cpu
+
+pytestmark = pytest.mark.gpu
+
+REL = 2e-2
+
+
+@pytest.fixture(scope="module")
+def mfa():
+    import my_flash_attn_cuda
+    assert torch.cuda.is_available()
+    return my_flash_attn_cuda
+
+
+def _rel(g, ref):
+    """max|g - ref| relative to the largest entry of ref (floored at 1e-2: a gradient that is
+    exactly zero, e.g. dq and dk for a single key, is compared absolutely)."""
+    ref = np.asarray(ref, np.float64)
+    return float(np.abs(np.asarray(g, np.float64) - ref).max() / max(np.abs(ref).max(), 1e-2))
+
+
+def _rounded(x, dtype):
+    return x.to(dtype).to(torch.float32).numpy()
+
+
+def _run(mfa, q, k, v, do, dtype, scale, causal):
+    qd, kd, vd, dod = (x.cuda().to(dtype) for x in (q, k, v, do))
+    out, lse = mfa.flash_attn_fwd(qd, kd, vd, scale=scale, return_lse=True, causal=causal)
+    return mfa.flash_attn_bwd(dod, qd, kd, vd, out, lse, scale=scale, causal=causal)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name", ["attn_bwd_1x2x100x64", "attn_bwd_1x2x129x128_causal", "attn_bwd_2x1x64x64_causal"])
+def test_bwd_vs_autograd_golden(mfa, name, dtype):
+    g = load_golden(name)
+    q, k, v, do = (torch.from_numpy(g[x]) for x in ("q", "k", "v", "dout"))
+    scale, causal = float(g["scale"]), bool(g["causal"])
+    got = _run(mfa, q, k, v, do, dtype, scale, causal)
+    ref = ref_cpu.attention_bwd_bhnd(*(_rounded(x, dtype) for x in (q, k, v, do)), scale=scale, causal=causal)
+    for nm, a, b in zip(("dq", "dk", "dv"), got, ref):
+        assert _rel(a.float().cpu().numpy(), b) <= REL, nm
+    # and against the stored autograd result of the unrounded inputs, where the rounding of the
+    # inputs adds to the distance
+    for nm, a in zip(("dq", "dk", "dv"), got):
+        assert _rel(a.float().cpu().numpy(), g[nm]) <= 4 * REL, nm
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [
+    (1, 1, 1, 64), (1, 2, 63, 128), (2, 3, 200, 64), (1, 2, 256, 128), (1, 2, 257, 128),
+    (1, 3, 1025, 64), (2, 2, 1000, 128), (1, 1, 2048, 128),
+])
+def test_bwd_vs_oracle(mfa, shape, dtype, causal):
+    B, H, N, d = shape
+    scale = d ** -0.5
+    torch.manual_seed(1)
+    q, k, v, do = (torch.randn(B, H, N, d, dtype=torch.float32) for _ in range(4))
+    got = _run(mfa, q, k, v, do, dtype, scale, causal)
+    ref = ref_cpu.attention_bwd_bhnd(*(_rounded(x, dtype) for x in (q, k, v, do)), scale=scale, causal=causal)
+    for nm, a, b in zip(("dq", "dk", "dv"), got, ref):
+        assert a.shape == shape and a.dtype == dtype
+        assert bool(torch.isfinite(a.float()).all()), nm
+        assert _rel(a.float().cpu().numpy(), b) <= REL, nm
+
+
+def test_bwd_unscaled_logits(mfa):
+    """scale = 1.0 (the reference's semantics for the forward): sharp softmax, large dS."""
+    B, H, N, d = 1, 2, 300, 64
+    torch.manual_seed(3)
+    q, k, v, do = (torch.randn(B, H, N, d, dtype=torch.float32) for _ in range(4))
+    got = _run(mfa, q, k, v, do, torch.bfloat16, 1.0, False)
+    ref = ref_cpu.attention_bwd_bhnd(*(_rounded(x, torch.bfloat16) for x in (q, k, v, do)), scale=1.0)
+    for nm, a, b in zip(("dq", "dk", "dv"), got, ref):
+        assert _rel(a.float().cpu().numpy(), b) <= REL, nm
+
+
+def test_autograd_function_matches_torch(mfa):
+    """flash_attn_func under torch.autograd against PyTorch's own SDPA backward on the GPU in
+    float32 (not the oracle: an end-to-end check of the autograd plumbing)."""
+    B, H, N, d = 2, 4, 384, 128
+    torch.manual_seed(4)
+    q, k, v = (torch.randn(B, H, N, d, device="cuda", dtype=torch.bfloat16, requires_grad=True) for _ in range(3))
+    do = torch.randn(B, H, N, d, device="cuda", dtype=torch.bfloat16)
+    out = mfa.flash_attn_func(q, k, v, scale=d ** -0.5, causal=True)
+    out.backward(do)
+    qf, kf, vf = (x.detach().float().requires_grad_(True) for x in (q, k, v))
+    ref = torch.nn.functional.scaled_dot_product_attention(qf, kf, vf, is_causal=True, scale=d ** -0.5)
+    ref.backward(do.float())
+    for a, b in ((q.grad, qf.grad), (k.grad, kf.grad), (v.grad, vf.grad)):
+        assert _rel(a.float().cpu().numpy(), b.cpu().numpy()) <= REL
+
+
+def test_bwd_headline_shape(mfa):
+    """Headline shape (bf16, B=4 H=32 N=4096 d=128): one whole head against the float64 oracle
+    (heads are independent), and on the full tensors two size-independent identities:
+    every gradient is finite, and sum over keys of dV equals sum over queries of dout
+    (each row of P sums to one)."""
+    B, H, N, d = 4, 32, 4096, 128
+    scale = d ** -0.5
+    torch.manual_seed(1)
+    q, k, v, do = (torch.randn(B, H, N, d, dtype=torch.bfloat16, device="cuda") for _ in range(4))
+    out, lse = mfa.flash_attn_fwd(q, k, v, scale=scale, return_lse=True)
+    dq, dk, dv = mfa.flash_attn_bwd(do, q, k, v, out, lse, scale=scale)
+    for t in (dq, dk, dv):
+        assert bool(torch.isfinite(t.float()).all())
+    lhs, rhs = dv.float().sum(dim=2), do.float().sum(dim=2)
+    assert float((lhs - rhs).abs().max()) <= REL * float(rhs.abs().max())
+    b, h = 2, 17
+    ref = ref_cpu.attention_bwd_bhnd(*(x[b, h].float().cpu().numpy() for x in (q, k, v, do)), scale=scale)
+    for nm, a, r in zip(("dq", "dk", "dv"), (dq, dk, dv), ref):
+        assert _rel(a[b, h].float().cpu().numpy(), r) <= REL, nm
+
+
+def test_bwd_errors(mfa):
+    q = torch.randn(1, 1, 64, 64, device="cuda", dtype=torch.float32)
+    lse = torch.zeros(1, 1, 64, device="cuda")
+    with pytest.raises(RuntimeError, match="float16 and bfloat16"):
+        mfa.flash_attn_bwd(q, q, q, q, q, lse)
+    qb = q.bfloat16()
+    with pytest.raises(RuntimeError, match="lse"):
+        mfa.flash_attn_bwd(qb, qb, qb, qb, qb, lse[:, :, :32])
+    with pytest.raises(RuntimeError, match="Wrong sizes"):
+        mfa.flash_attn_bwd(qb, qb, qb[:, :, :32], qb, qb, lse)
