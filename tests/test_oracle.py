@@ -87,6 +87,31 @@ def test_causal_oracles_vs_sdpa_golden(name, c_oracle):
     assert np.abs(lse[..., 0] - scale * np.einsum("...d,...d->...", q[..., 0, :].astype(np.float64), k[..., 0, :].astype(np.float64))).max() < 1e-12
 
 
+@pytest.mark.parametrize("name", ["attn_bwd_1x2x100x64", "attn_bwd_1x2x129x128_causal", "attn_bwd_2x1x64x64_causal"])
+def test_backward_oracle_vs_autograd_golden(name):
+    """The backward has no counterpart in the reference; its oracle is pinned against the stored
+    float64 autograd gradients of torch's scaled_dot_product_attention, and checked here by
+    central differences of the forward oracle as well."""
+    g = load_golden(name)
+    q, k, v, do = g["q"], g["k"], g["v"], g["dout"]
+    scale, causal = float(g["scale"]), bool(g["causal"])
+    dq, dk, dv = ref_cpu.attention_bwd_bhnd(q, k, v, do, scale=scale, causal=causal)
+    for got, nm in ((dq, "dq"), (dk, "dk"), (dv, "dv")):
+        assert np.abs(got - g[nm]).max() <= 1e-6 * max(1.0, np.abs(g[nm]).max())   # (fixture stored as float32)
+    # directional derivative: <dout, (O(x + e t) - O(x - e t)) / 2e> = <grad, t>
+    rng = np.random.default_rng(0)
+    e = 1e-6
+    for x, grad, idx in ((q, dq, 0), (k, dk, 1), (v, dv, 2)):
+        t = rng.standard_normal(x.shape)
+        args_p = [q.astype(np.float64), k.astype(np.float64), v.astype(np.float64)]
+        args_m = [a.copy() for a in args_p]
+        args_p[idx] = args_p[idx] + e * t
+        args_m[idx] = args_m[idx] - e * t
+        num = ((ref_cpu.attention_bhnd(*args_p, scale=scale, causal=causal)
+                - ref_cpu.attention_bhnd(*args_m, scale=scale, causal=causal)) * do).sum() / (2 * e)
+        assert abs(num - (grad * t).sum()) <= 1e-6 * max(1.0, abs(num))
+
+
 def test_flash_block_sizes_match_reference_formula():
     # Bc = ceil(64 KiB / 4d), Br = min(Bc, d)  (tests/test_flash_attn.py:53-55)
     assert ref_cpu.flash_block_sizes(64) == (64, 256)
