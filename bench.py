@@ -18,7 +18,7 @@ collective on the timed path.  Rank 0 prints ONE JSON line:
                    against 8 TB/s HBM peak (rank 0, N=1 only)
   softmax_1024     my_softmax at 1024 x 1024 timed the way the reference's benchmark.py does, beside the
                    reference's published T4 numbers (the only timings it publishes)
-  cpu_config1      torch CPU timings of BASELINE config 1 (softmax 1024^2, naive attention
+  cpu_config1      torch CPU timings of the CPU reference configuration (softmax 1024^2, naive attention
                    N=128 d=64), for reference beside the GPU numbers
   attention_f32    the float32 path (float64-MFMA logits + float32-MFMA P.V): the reference's
                    my_attention(Q, K_t, V) at N=128 d=64 (config 1) and N=1024 d=64 (its largest
@@ -49,7 +49,7 @@ HBM_PEAK_GBS = 8000.0       # HBM3E peak
 
 WORKLOADS = {
     # name: (B, H, N, d, dtype) -- per GPU
-    "headline": (4, 32, 4096, 128, torch.bfloat16),    # BASELINE.json configs[3], the metric's config
+    "headline": (4, 32, 4096, 128, torch.bfloat16),    # the configuration the headline metric is quoted on
     "config3": (8, 16, 1024, 64, torch.float16),       # configs[2]
     "config5": (1, 32, 16384, 128, torch.bfloat16),    # configs[4]: the shard one of 8 GPUs gets
 }
@@ -215,7 +215,8 @@ def cpu_baseline(B, H, N, d, scale, budget_s=12.0):
 
 
 def cpu_config1():
-    """BASELINE config 1 on the host with torch CPU ops (not part of any GPU number)."""
+    """The CPU reference configuration (softmax 1024^2, naive attention N=128 d=64) on the host
+    with torch CPU ops (not part of any GPU number)."""
     torch.manual_seed(1)
     x = torch.randn(1024, 1024)
     q, k, v = (torch.randn(128, 64) for _ in range(3))
@@ -243,7 +244,7 @@ def main():
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--scale", default="rsqrt_d", choices=["rsqrt_d", "one"],
                     help="logit scale: d^-0.5 (usual) or 1.0 (the reference's unscaled semantics)")
-    ap.add_argument("--causal", action="store_true", help="causal mask (not the BASELINE metric; counts half the flops)")
+    ap.add_argument("--causal", action="store_true", help="causal mask (not the headline metric; counts half the flops)")
     ap.add_argument("--no-extras", action="store_true", help="skip softmax sweep and CPU baselines")
     args = ap.parse_args()
 

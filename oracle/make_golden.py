@@ -16,7 +16,7 @@ What it does
    reference's ``_softmax``, ``_attention_forward`` and
    ``_flash_attention_forward`` plus the PyTorch ops its tests compare against
    (``F.softmax``, ``scaled_dot_product_attention(scale=1.0)``) on every shape
-   its tests use, plus BASELINE config 1 (1024x1024 softmax, N=128 d=64).
+   its tests use, plus the CPU reference configuration (1024x1024 softmax, N=128 d=64).
 3. Checks the numpy oracle (oracle/ref_cpu.py) and the C oracle
    (oracle/oracle.c) against all of them; aborts if any disagree beyond
    the stated bound.

@@ -214,7 +214,7 @@ def _sampled_check(mfa, c_oracle, B, H, N, d, dtype, scale, heads, nrows, seed=1
 
 
 def test_config3_f16_full_size(mfa, c_oracle):
-    """BASELINE config 3: f16, B=8 H=16 N=1024 d=64."""
+    """The f16 benchmark configuration: B=8 H=16 N=1024 d=64."""
     for scale in (1.0, 64 ** -0.5):
         *_, worst = _sampled_check(mfa, c_oracle, 8, 16, 1024, 64, torch.float16, scale,
                                    heads=[(0, 0), (3, 7), (7, 15)], nrows=200)
@@ -222,7 +222,7 @@ def test_config3_f16_full_size(mfa, c_oracle):
 
 
 def test_headline_bf16_full_size(mfa, c_oracle):
-    """BASELINE headline: bf16, B=4 H=32 N=4096 d=128 -- sampled rows against all 4096 keys,
+    """The headline benchmark configuration: bf16, B=4 H=32 N=4096 d=128 -- sampled rows against all 4096 keys,
     plus size-independent properties on the full tensors."""
     B, H, N, d = 4, 32, 4096, 128
     for scale in (1.0, d ** -0.5):
@@ -249,7 +249,7 @@ def test_headline_bf16_full_size(mfa, c_oracle):
 
 
 def test_config5_shard_bf16(mfa, c_oracle):
-    """BASELINE config 5, the shard one of 8 GPUs gets: bf16, (B*H)/8 = 32 heads, N=16384, d=128."""
+    """The scaling configuration, the shard one of 8 GPUs gets: bf16, (B*H)/8 = 32 heads, N=16384, d=128."""
     *_, worst = _sampled_check(mfa, c_oracle, 1, 32, 16384, 128, torch.bfloat16, 128 ** -0.5,
                                heads=[(0, 0), (0, 31)], nrows=48)
     assert worst <= LP_ATOL

@@ -4,7 +4,7 @@ Mirrors the reference's test_softmax_kernel (tests/test_flash_attn.py:132-151:
 (255, 516), my_softmax(x, 5) vs F.softmax, values in [0, 1], rows sum to 1) and
 adds the shapes it lists but has commented out (:134-135), ragged and unaligned
 widths, every register-resident dispatch class, the long-row streaming kernel,
-and BASELINE's sweep sizes through size-independent properties.
+and the benchmark's sweep sizes (4096^2 ... 32768^2) through size-independent properties.
 
 Tolerance: float32, |out - oracle| <= 1e-5 absolute against the float64 oracle and
 against the reference's golden outputs (the reference's own bar is 1e-4).
@@ -112,7 +112,7 @@ def test_nondefault_stream(mfa, c_oracle):
 
 @pytest.mark.parametrize("n", [4096, 8192, 16384, 32768])
 def test_sweep_sizes_properties(mfa, c_oracle, n):
-    """BASELINE's n x n sweep: properties over the whole matrix, oracle on sampled rows."""
+    """The benchmark's n x n sweep: properties over the whole matrix, oracle on sampled rows."""
     torch.manual_seed(1)
     x = torch.randn(n, n, dtype=torch.float32, device="cuda")
     out = mfa.my_softmax(x, 1)
