@@ -33,6 +33,8 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float kLog2e = 1.4426950408889634f;
+template <int V> struct IC { static constexpr int value = V; };
+
 constexpr int kTile = 64;            // rows of a streamed tile (keys in dQ, queries in dK/dV)
 
 // ---------------------------------------------------------------- delta = rowsum(dO o O)
@@ -299,7 +301,37 @@ attn_bwd_dkv_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T*
     stage_write(0);
     __syncthreads();
 
+    // Per-lane bases of the fragment reads; everything else in an address is an immediate.
+    //   row read of block qb, k-step ks: row 32qb + r, chunk 2ks + h
+    //   transposing read of (qb, st, db): rows 32qb + 16st + 8hi + 4h + tq, chunk 4db + 2tg1 + (tp >> 1)
+    constexpr int SUB_B = 16 * D;
     const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
+    int rbase[2], tbase[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        rbase[e] = SUB_B * (r >> 3) + 64 * (r & 7) + 16 * ((2 * e + h) ^ ((r >> 2) & 3));
+        tbase[e] = 64 * (4 * h + tq) + 16 * ((2 * tg1 + (tp >> 1)) ^ (2 * e + h)) + 8 * (tp & 1) + SUB_B * e;
+    }
+    // An MFMA sequence as one software-pipelined stream: the LDS fragment of MFMA i + FW is
+    // requested when MFMA i issues (with one wave per SIMD nothing else hides the LDS latency),
+    // and the order is pinned so that the scheduler does not move each read back to its use.
+    constexpr int FW = 8;
+    // `after(i)` runs behind MFMA i: vector work placed there executes in the MFMA's shadow.
+    auto stream = [&](auto n_, auto&& frag, auto&& mma, auto&& after) __attribute__((always_inline)) {
+        constexpr int NFR = decltype(n_)::value;
+        s16x8 win[FW];
+#pragma unroll
+        for (int i = 0; i < FW && i < NFR; ++i) win[i] = frag(i);
+#pragma unroll
+        for (int i = 0; i < NFR; ++i) {
+            const s16x8 a = win[i % FW];
+            mma(i, a);
+            if (i + FW < NFR) win[i % FW] = frag(i + FW);
+            after(i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto nothing = [](int) __attribute__((always_inline)) {};
 
     for (int t = t0; t < T_all; ++t) {
         const int buf = (t - t0) & 1;
@@ -310,76 +342,106 @@ attn_bwd_dkv_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T*
         const float* lse2b = stat + buf * 2 * kTile;
         const float* delb = lse2b + kTile;
 
-        // ---- S = Q K^T and dP = dO V^T (query blocks x k-steps): key on the lane
-        f32x16 s[2], dp[2];
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { s[qb][i] = 0.f; dp[qb][i] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const s16x8 a = *reinterpret_cast<const s16x8*>(Qb + img_off<D>(32 * qb + r, 2 * ks + h));
-                s[qb] = M::run(a, kf[ks], s[qb]);
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const s16x8 a = *reinterpret_cast<const s16x8*>(dOb + img_off<D>(32 * qb + r, 2 * ks + h));
-                dp[qb] = M::run(a, vf[ks], dp[qb]);
-            }
-        }
-
-        // ---- P and dS; accumulator register i of block qb is query 32qb + (i&3) + 8(i>>2) + 4h
+        // The tile's 64 queries are two blocks of 32, and the work of the two blocks is staggered so
+        // that the vector part of one block runs in the shadow of the other block's MFMAs:
+        //   A  S0, dP0                          (MFMA only)
+        //   B  S1, dP1      with P0, dS0        (one or two elements behind every MFMA)
+        //   C  dV, dK += block 0   with P1, dS1
+        //   D  dV, dK += block 1
+        // S = Q K^T and dP = dO V^T put the key on the lane; accumulator register i of block qb
+        // is query 32qb + (i & 3) + 8 (i >> 2) + 4h, so the rows' lse and delta come as four
+        // broadcast float4 reads per block.
         const bool edge = qt0 + kTile > N || k0 + BK > N || (CAUSAL && k0 + BK - 1 > qt0);
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+        f32x16 s[2], dp[2];
+        f32x4 l4[2][4], d4[2][4];
+        vec8 pb[4], sb[4];
+        auto load_stat = [&](int qb) __attribute__((always_inline)) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int qi = 32 * qb + 8 * g + 4 * h;
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse2b + qi);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(delb + qi);
+                l4[qb][g] = *reinterpret_cast<const f32x4*>(lse2b + 32 * qb + 8 * g + 4 * h);
+                d4[qb][g] = *reinterpret_cast<const f32x4*>(delb + 32 * qb + 8 * g + 4 * h);
+            }
+        };
+        auto pds = [&](int qb, int i) __attribute__((always_inline)) {     // P and dS of one element
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][i], sl2, -l4[qb][i >> 2][i & 3]));
+            s[qb][i] = p;
+            dp[qb][i] = p * (dp[qb][i] - d4[qb][i >> 2][i & 3]);
+        };
+        auto finish = [&](int qb) __attribute__((always_inline)) {         // edge mask, then 16-bit operands
+            if (edge) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = 4 * g + j;
-                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][i], sl2, -l4[j]));
-                    if (edge) {
-                        const int qglob = qt0 + qi + j;
-                        if (qglob >= N || krow >= N || (CAUSAL && krow > qglob)) p = 0.f;
-                    }
-                    s[qb][i] = p;
-                    dp[qb][i] = p * (dp[qb][i] - d4[j]);
+                for (int i = 0; i < 16; ++i) {
+                    const int qglob = qt0 + 32 * qb + 8 * (i >> 2) + 4 * h + (i & 3);
+                    if (qglob >= N || krow >= N || (CAUSAL && krow > qglob)) { s[qb][i] = 0.f; dp[qb][i] = 0.f; }
                 }
             }
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    pb[2 * qb + st][j] = (T)s[qb][8 * st + j];
+                    sb[2 * qb + st][j] = (T)dp[qb][8 * st + j];
+                }
+        };
+        // fragment i of block qb's first half: group i / KS: 0 = Q rows for S, 1 = dO rows for dP
+        auto row_frag = [&](int qb, int i) __attribute__((always_inline)) -> s16x8 {
+            const int which = i / KS, ks = i % KS;
+            const char* tile = which ? dOb : Qb;
+            return *reinterpret_cast<const s16x8*>(tile + rbase[ks & 1] + SUB_B * 4 * qb + 512 * (ks >> 1));
+        };
+        auto row_mma = [&](int qb, int i, s16x8 a) __attribute__((always_inline)) {
+            const int which = i / KS, ks = i % KS;
+            if (which) dp[qb] = M::run(a, vf[ks], dp[qb]);
+            else s[qb] = M::run(a, kf[ks], s[qb]);
+        };
+        // fragment i of block qb's second half: k-step st = i / (2 DB), then (db, which): 0 = dO^T for dV, 1 = Q^T for dK
+        auto tr_frag = [&](int qb, int i) __attribute__((always_inline)) -> s16x8 {
+            const int st = i / (2 * DB), db = (i / 2) % DB, which = i & 1;
+            const char* tile = which ? Qb : dOb;
+            const int imm = SUB_B * 2 * (2 * qb + st) + 512 * db;
+            const s16x4 lo = lds_read_tr(tile + tbase[0] + imm);
+            const s16x4 hi = lds_read_tr(tile + tbase[1] + imm);
+            s16x8 a;
+            a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
+            a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
+            return a;
+        };
+        auto tr_mma = [&](int qb, int i, s16x8 a) __attribute__((always_inline)) {
+            const int st = i / (2 * DB), db = (i / 2) % DB, which = i & 1;
+            if (which) dk[db] = M::run(a, sb[2 * qb + st], dk[db]);
+            else dv[db] = M::run(a, pb[2 * qb + st], dv[db]);
+        };
+        constexpr int EPM = 16 / (2 * KS);            // elements per MFMA step (2 KS = 4 DB steps per half)
+        static_assert(2 * KS == 4 * DB && EPM * 2 * KS == 16, "phases of equal length");
 
-        // ---- dV^T += dO^T P and dK^T += Q^T dS : 4 k-steps of 16 queries x DB row blocks
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                vec8 pb, sb;
+            for (int i = 0; i < 16; ++i) { s[qb][i] = 0.f; dp[qb][i] = 0.f; }
+        load_stat(0);
+        stream(IC<2 * KS>{},                                                                       // A
+               [&](int i) __attribute__((always_inline)) -> s16x8 { return row_frag(0, i); },
+               [&](int i, s16x8 a) __attribute__((always_inline)) { row_mma(0, i, a); }, nothing);
+        load_stat(1);
+        stream(IC<2 * KS>{},                                                                       // B
+               [&](int i) __attribute__((always_inline)) -> s16x8 { return row_frag(1, i); },
+               [&](int i, s16x8 a) __attribute__((always_inline)) { row_mma(1, i, a); },
+               [&](int i) __attribute__((always_inline)) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { pb[j] = (T)s[qb][8 * st + j]; sb[j] = (T)dp[qb][8 * st + j]; }
-                const int r0 = 32 * qb + 16 * st + 4 * h + tq;
+                   for (int e = 0; e < EPM; ++e) pds(0, EPM * i + e);
+               });
+        finish(0);
+        stream(IC<4 * DB>{},                                                                       // C
+               [&](int i) __attribute__((always_inline)) -> s16x8 { return tr_frag(0, i); },
+               [&](int i, s16x8 a) __attribute__((always_inline)) { tr_mma(0, i, a); },
+               [&](int i) __attribute__((always_inline)) {
 #pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const int ch = 4 * db + 2 * tg1 + (tp >> 1);
-                    {
-                        const s16x4 lo = lds_read_tr(dOb + img_off<D>(r0, ch) + 8 * (tp & 1));
-                        const s16x4 hi = lds_read_tr(dOb + img_off<D>(r0 + 8, ch) + 8 * (tp & 1));
-                        s16x8 a;
-                        a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
-                        a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
-                        dv[db] = M::run(a, pb, dv[db]);
-                    }
-                    {
-                        const s16x4 lo = lds_read_tr(Qb + img_off<D>(r0, ch) + 8 * (tp & 1));
-                        const s16x4 hi = lds_read_tr(Qb + img_off<D>(r0 + 8, ch) + 8 * (tp & 1));
-                        s16x8 a;
-                        a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
-                        a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
-                        dk[db] = M::run(a, sb, dk[db]);
-                    }
-                }
-            }
+                   for (int e = 0; e < EPM; ++e) pds(1, EPM * i + e);
+               });
+        finish(1);
+        stream(IC<4 * DB>{},                                                                       // D
+               [&](int i) __attribute__((always_inline)) -> s16x8 { return tr_frag(1, i); },
+               [&](int i, s16x8 a) __attribute__((always_inline)) { tr_mma(1, i, a); }, nothing);
 
         stage_write(buf ^ 1);
         __syncthreads();
