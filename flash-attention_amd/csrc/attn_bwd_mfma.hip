@@ -38,9 +38,12 @@ template <int V> struct IC { static constexpr int value = V; };
 constexpr int kTile = 64;            // rows of a streamed tile (keys in dQ, queries in dK/dV)
 
 // ---------------------------------------------------------------- delta = rowsum(dO o O)
+// (and the row statistic in base 2, lse * log2(e), next to it: the two per-row scalars the
+// other kernels consume, in one workspace of 2 * rows floats: [delta | lse2])
 template <typename T, int D>
 __global__ void __launch_bounds__(256)
-attn_bwd_delta_kernel(const T* __restrict__ Og, const T* __restrict__ dOg, float* __restrict__ DELg, long long rows) {
+attn_bwd_delta_kernel(const T* __restrict__ Og, const T* __restrict__ dOg, const float* __restrict__ LSEg,
+                      float* __restrict__ DELg, long long rows) {
     using vec8 = typename Mma<T>::vec8;
     constexpr int CPR = D / 8;                     // 16-byte chunks per row = threads per row
     const long long row = (long long)blockIdx.x * (256 / CPR) + threadIdx.x / CPR;
@@ -54,7 +57,10 @@ attn_bwd_delta_kernel(const T* __restrict__ Og, const T* __restrict__ dOg, float
     }
 #pragma unroll
     for (int m = 1; m < CPR; m <<= 1) acc += __shfl_xor(acc, m);
-    if (row < rows && ch == 0) DELg[row] = acc;
+    if (row < rows && ch == 0) {
+        DELg[row] = acc;
+        DELg[rows + row] = LSEg[row] * kLog2e;
+    }
 }
 
 // ---------------------------------------------------------------- shared tile staging
@@ -230,7 +236,7 @@ attn_bwd_dq_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* 
 template <typename T, int D, bool CAUSAL>
 __global__ void __launch_bounds__(256, 1)
 attn_bwd_dkv_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* __restrict__ Vg,
-                    const T* __restrict__ dOg, const float* __restrict__ LSEg, const float* __restrict__ DELg,
+                    const T* __restrict__ dOg, const float* __restrict__ LSE2g, const float* __restrict__ DELg,
                     T* __restrict__ dKg, T* __restrict__ dVg, int N, int nkblk, int nwg, float scale) {
     using M = Mma<T>;
     using vec8 = typename M::vec8;
@@ -256,7 +262,7 @@ attn_bwd_dkv_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T*
     const size_t hoff = (size_t)head * (size_t)N * D;
     const T* Qh = Qg + hoff;
     const T* dOh = dOg + hoff;
-    const float* lseh = LSEg + (size_t)head * N;
+    const float* lseh = LSE2g + (size_t)head * N;    // lse * log2(e), written by the delta kernel
     const float* delh = DELg + (size_t)head * N;
 
     const int krow = k0 + wave * 32 + r;
@@ -269,24 +275,41 @@ attn_bwd_dkv_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T*
     }
     const float sl2 = scale * kLog2e;
 
-    TileStage<T, D, THREADS> qst, dst;
-    float lse_st = 0.f, del_st = 0.f;
-    auto stage_load = [&](int q0) __attribute__((always_inline)) {
-        qst.load(Qh, q0, N, tid);
-        dst.load(dOh, q0, N, tid);
-        if (tid < kTile) {
-            const int g = min(q0 + tid, N - 1);
-            lse_st = lseh[g] * kLog2e;
-            del_st = delh[g];
+    // Q and dO tiles (and the 64 rows' lse2 / delta) go HBM/L2 -> LDS directly (buffer_load ... lds):
+    // one wave-instruction fills 1 KiB of a tile image, lane L at base + 16 L, so the image is
+    // produced by choosing each lane's SOURCE chunk, as in the forward kernel.  Rows past N read
+    // as zero through the buffer bounds check (and are masked as edge rows).
+    constexpr int CPR = D / 8, LPT = kTile * CPR / THREADS;
+    const unsigned head_bytes = (unsigned)N * D * 2;
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc((void*)Qh, 0, head_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)dOh, 0, head_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)lseh, 0, (unsigned)N * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)delh, 0, (unsigned)N * 4, 0x00020000);
+    int st_goff[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const int u = 64 * (wave * LPT + i) + lane;
+        const int grp8 = u / (16 * D / 16), within = u % (16 * D / 16);
+        const int row = 8 * grp8 + ((within & 31) >> 2);
+        const int ch = 4 * (within >> 5) + ((within & 3) ^ ((row >> 2) & 3));
+        st_goff[i] = (row * D + ch * 8) * 2;
+    }
+    // (the host pass of hipcc silently drops a kernel whose body names this builtin; the calls
+    // only exist in the device pass)
+    auto fetch_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (lds_void*)(lds + buf * TILE_B + 1024 * (wave * LPT + i)),
+                                                     16, st_goff[i], tile * TILE_B, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ors, (lds_void*)(lds + (2 + buf) * TILE_B + 1024 * (wave * LPT + i)),
+                                                     16, st_goff[i], tile * TILE_B, 0, 0);
         }
-    };
-    auto stage_write = [&](int buf) __attribute__((always_inline)) {
-        qst.write(lds + buf * TILE_B, tid);
-        dst.write(lds + (2 + buf) * TILE_B, tid);
-        if (tid < kTile) {
-            stat[buf * 2 * kTile + tid] = lse_st;
-            stat[buf * 2 * kTile + kTile + tid] = del_st;
+        if (wave == 0) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(lrs, (lds_void*)(stat + buf * 2 * kTile), 4, lane * 4, tile * kTile * 4, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void*)(stat + buf * 2 * kTile + kTile), 4, lane * 4, tile * kTile * 4, 0, 0);
         }
+#endif
     };
 
     f32x16 dk[DB], dv[DB];
@@ -297,8 +320,8 @@ attn_bwd_dkv_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T*
 
     const int T_all = (N + kTile - 1) / kTile;
     const int t0 = CAUSAL ? k0 / kTile : 0;        // causal: queries before the block's first key see none of it
-    stage_load(t0 * kTile);
-    stage_write(0);
+    fetch_tile(t0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // Per-lane bases of the fragment reads; everything else in an address is an immediate.
@@ -336,7 +359,9 @@ attn_bwd_dkv_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T*
     for (int t = t0; t < T_all; ++t) {
         const int buf = (t - t0) & 1;
         const int qt0 = t * kTile;
-        stage_load(qt0 + kTile);
+        // the next tile into the other buffer (last read before the previous barrier); unconditional,
+        // a tile past the end reads zeros.  It has the whole tile's compute to land.
+        fetch_tile(t + 1, buf ^ 1);
         const char* Qb = lds + buf * TILE_B;
         const char* dOb = lds + (2 + buf) * TILE_B;
         const float* lse2b = stat + buf * 2 * kTile;
@@ -443,7 +468,7 @@ attn_bwd_dkv_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T*
                [&](int i) __attribute__((always_inline)) -> s16x8 { return tr_frag(1, i); },
                [&](int i, s16x8 a) __attribute__((always_inline)) { tr_mma(1, i, a); }, nothing);
 
-        stage_write(buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next tile are in
         __syncthreads();
     }
 
@@ -474,18 +499,19 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     const T* dO = static_cast<const T*>(dout);
     const int64_t rows = heads * N;
     constexpr int RPB = 256 / (D / 8);
-    hipLaunchKernelGGL((attn_bwd_delta_kernel<T, D>), dim3((unsigned)cdiv(rows, RPB)), dim3(256), 0, s, O, dO, delta, (long long)rows);
+    hipLaunchKernelGGL((attn_bwd_delta_kernel<T, D>), dim3((unsigned)cdiv(rows, RPB)), dim3(256), 0, s, O, dO, lse, delta, (long long)rows);
+    const float* lse2 = delta + rows;
 
     const int64_t nqblk = cdiv(N, 256), nkblk = cdiv(N, 128);
     const int64_t nq = heads * nqblk, nk = heads * nkblk;
     if (nq > 0x7fffffffLL || nk > 0x7fffffffLL) return fail(MYFA_E_UNSUPPORTED, "attention backward: too many workgroups");
     if (causal) {
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, true>), dim3((unsigned)nk), dim3(256), 0, s, Q, K, V, dO, lse, delta,
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, true>), dim3((unsigned)nk), dim3(256), 0, s, Q, K, V, dO, lse2, delta,
                            static_cast<T*>(dk), static_cast<T*>(dv), (int)N, (int)nkblk, (int)nk, scale);
         hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, true>), dim3((unsigned)nq), dim3(512), 0, s, Q, K, V, dO, lse, delta,
                            static_cast<T*>(dq), (int)N, (int)nqblk, (int)nq, scale);
     } else {
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, false>), dim3((unsigned)nk), dim3(256), 0, s, Q, K, V, dO, lse, delta,
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, false>), dim3((unsigned)nk), dim3(256), 0, s, Q, K, V, dO, lse2, delta,
                            static_cast<T*>(dk), static_cast<T*>(dv), (int)N, (int)nkblk, (int)nk, scale);
         hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, false>), dim3((unsigned)nq), dim3(512), 0, s, Q, K, V, dO, lse, delta,
                            static_cast<T*>(dq), (int)N, (int)nqblk, (int)nq, scale);
@@ -496,7 +522,7 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
 }  // namespace
 
 // dtype: MYFA_F16 or MYFA_BF16; d: 64 or 128; heads = B*H.  `delta` is a caller-provided
-// float32 workspace of heads * N elements (the library allocates nothing).
+// float32 workspace of 2 * heads * N elements (the library allocates nothing).
 int attn_bwd_mfma(const void* q, const void* k, const void* v, const void* o, const float* lse, const void* dout,
                   void* dq, void* dk, void* dv, float* delta, int64_t heads, int64_t N, int64_t d,
                   float scale, int dtype, bool causal, hipStream_t s) {

@@ -132,8 +132,9 @@ int myfa_attn_fwd_bhnd_ex(const void* q, const void* k, const void* v, void* o, 
  * Backward of myfa_attn_fwd_bhnd_ex for MYFA_F16 / MYFA_BF16, d in {64, 128}:
  * given the forward's inputs, its output `o`, its row log-sum-exp `lse` and the
  * gradient `dout` of the output, writes dq, dk, dv (same shape and dtype as q, k, v).
- * `delta_ws` is a float32 workspace of B*H*N elements provided by the caller (it
- * receives rowsum(dout o o)); the library allocates nothing.  flags as in the forward.
+ * `delta_ws` is a float32 workspace of 2*B*H*N elements provided by the caller (it
+ * receives rowsum(dout o o) and lse in base 2); the library allocates nothing.
+ * flags as in the forward.
  * No counterpart in the reference, which has neither a fused forward nor a
  * backward (csrc/my_flash_attn/flash_attention.cu:23-69 is a stub); the math is the
  * derivative of the forward it sketches, checked against autograd of PyTorch's
