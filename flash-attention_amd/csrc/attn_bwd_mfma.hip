@@ -63,34 +63,6 @@ attn_bwd_delta_kernel(const T* __restrict__ Og, const T* __restrict__ dOg, const
     }
 }
 
-// ---------------------------------------------------------------- shared tile staging
-// A [kTile][D] tile goes global -> registers -> LDS in the image of attn_mfma_common.h; rows
-// past N repeat row N-1 (finite values; whatever they produce is masked).
-template <typename T, int D, int THREADS>
-struct TileStage {
-    static constexpr int CPR = D / 8;
-    static constexpr int LPT = kTile * CPR / THREADS;
-    u32x4 st[LPT];
-    __device__ __forceinline__ void load(const T* base, int row0, int N, int tid) {
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const int id = tid + THREADS * i;
-            const int row = id / CPR, ch = id % CPR;
-            int g = row0 + row;
-            g = g < N ? g : N - 1;
-            st[i] = *reinterpret_cast<const u32x4*>(base + (size_t)g * D + ch * 8);
-        }
-    }
-    __device__ __forceinline__ void write(char* tile, int tid) const {
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const int id = tid + THREADS * i;
-            const int row = id / CPR, ch = id % CPR;
-            *reinterpret_cast<u32x4*>(tile + img_off<D>(row, ch)) = st[i];
-        }
-    }
-};
-
 // ---------------------------------------------------------------- dQ
 template <typename T, int D, bool CAUSAL>
 __global__ void __launch_bounds__(512, 2)
@@ -133,88 +105,162 @@ attn_bwd_dq_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* 
     const float delta = DELg[(size_t)head * N + qrow_c];
     const float sl2 = scale * kLog2e;
 
-    TileStage<T, D, THREADS> kst, vst;
     f32x16 dq[DB];
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int i = 0; i < 16; ++i) dq[db][i] = 0.f;
 
+    // K and V tiles go HBM/L2 -> LDS directly (buffer_load ... lds), the image produced by choosing
+    // each lane's source chunk; rows past N read as zero through the buffer bounds check.
+    constexpr int CPR = D / 8, LPT = kTile * CPR / THREADS, SUB_B = 16 * D;
+    const unsigned head_bytes = (unsigned)N * D * 2;
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, head_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, head_bytes, 0x00020000);
+    int st_goff[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const int u = 64 * (wave * LPT + i) + lane;
+        const int grp8 = u / (SUB_B / 16), within = u % (SUB_B / 16);
+        const int row = 8 * grp8 + ((within & 31) >> 2);
+        const int ch = 4 * (within >> 5) + ((within & 3) ^ ((row >> 2) & 3));
+        st_goff[i] = (row * D + ch * 8) * 2;
+    }
+    // (the host pass of hipcc silently drops a kernel whose body names this builtin; the calls
+    // only exist in the device pass)
+    auto fetch_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_void*)(lds + buf * TILE_B + 1024 * (wave * LPT + i)),
+                                                     16, st_goff[i], tile * TILE_B, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_void*)(lds + (2 + buf) * TILE_B + 1024 * (wave * LPT + i)),
+                                                     16, st_goff[i], tile * TILE_B, 0, 0);
+        }
+#endif
+    };
+
     const int T_all = (N + kTile - 1) / kTile;
     const int ntiles = CAUSAL ? min(T_all, (q0 + BQ) / kTile) : T_all;
-    kst.load(Kh, 0, N, tid);
-    vst.load(Vh, 0, N, tid);
-    kst.write(lds, tid);
-    vst.write(lds + 2 * TILE_B, tid);
+    fetch_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // Per-lane bases of the fragment reads; everything else in an address is an immediate.
     const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
+    int rbase[2], tbase[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        rbase[e] = SUB_B * (r >> 3) + 64 * (r & 7) + 16 * ((2 * e + h) ^ ((r >> 2) & 3));
+        tbase[e] = 64 * (4 * h + tq) + 16 * ((2 * tg1 + (tp >> 1)) ^ (2 * e + h)) + 8 * (tp & 1) + SUB_B * e;
+    }
+    // An MFMA sequence as one software-pipelined stream (LDS fragment of MFMA i + FW requested
+    // when MFMA i issues, order pinned); `after(i)` runs in the shadow of MFMA i.
+    constexpr int FW = 4;
+    auto stream = [&](auto n_, auto&& frag, auto&& mma, auto&& after) __attribute__((always_inline)) {
+        constexpr int NFR = decltype(n_)::value;
+        s16x8 win[FW];
+#pragma unroll
+        for (int i = 0; i < FW && i < NFR; ++i) win[i] = frag(i);
+#pragma unroll
+        for (int i = 0; i < NFR; ++i) {
+            const s16x8 a = win[i % FW];
+            mma(i, a);
+            if (i + FW < NFR) win[i % FW] = frag(i + FW);
+            after(i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto nothing = [](int) __attribute__((always_inline)) {};
 
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         const int kv0 = t * kTile;
-        // always issued (rows clamped inside): a load under a condition makes hipcc guard the
-        // staging registers with a full wait
-        kst.load(Kh, kv0 + kTile, N, tid);
-        vst.load(Vh, kv0 + kTile, N, tid);
+        // the next tile into the other buffer (last read before the previous barrier); unconditional,
+        // a tile past the end reads zeros
+        fetch_tile(t + 1, buf ^ 1);
         const char* Kb = lds + buf * TILE_B;
         const char* Vb = lds + (2 + buf) * TILE_B;
 
-        // ---- S^T = K Q^T and dP^T = V dO^T (key blocks x k-steps): query on the lane
+        // The tile's 64 keys are two blocks of 32, staggered so that the vector part of one block
+        // runs in the shadow of the other block's MFMAs:
+        //   A  S0^T, dP0^T                 B  S1^T, dP1^T   with dS0^T
+        //   C  dQ^T += block 0  with dS1^T  D  dQ^T += block 1
+        // S^T = K Q^T and dP^T = V dO^T put the query on the lane, so lse2 and delta are scalars.
+        const bool edge = kv0 + kTile > N || (CAUSAL && kv0 + kTile - 1 > q0 + 32 * wave);
         f32x16 s[2], dp[2];
+        vec8 sb[4];
+        auto pds = [&](int kb, int i) __attribute__((always_inline)) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], sl2, -lse2));
+            s[kb][i] = p * (dp[kb][i] - delta);
+        };
+        auto finish = [&](int kb) __attribute__((always_inline)) {
+            if (edge) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kv0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= N || (CAUSAL && key > qrow)) s[kb][i] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sb[2 * kb + st][j] = (T)s[kb][8 * st + j];
+        };
+        auto row_frag = [&](int kb, int i) __attribute__((always_inline)) -> s16x8 {
+            const int which = i / KS, ks = i % KS;
+            const char* tile = which ? Vb : Kb;
+            return *reinterpret_cast<const s16x8*>(tile + rbase[ks & 1] + SUB_B * 4 * kb + 512 * (ks >> 1));
+        };
+        auto row_mma = [&](int kb, int i, s16x8 a) __attribute__((always_inline)) {
+            const int which = i / KS, ks = i % KS;
+            if (which) dp[kb] = M::run(a, dof[ks], dp[kb]);
+            else s[kb] = M::run(a, qf[ks], s[kb]);
+        };
+        auto tr_frag = [&](int kb, int i) __attribute__((always_inline)) -> s16x8 {
+            const int st = i / DB, db = i % DB;
+            const int imm = SUB_B * 2 * (2 * kb + st) + 512 * db;
+            const s16x4 lo = lds_read_tr(Kb + tbase[0] + imm);
+            const s16x4 hi = lds_read_tr(Kb + tbase[1] + imm);
+            s16x8 a;
+            a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
+            a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
+            return a;
+        };
+        auto tr_mma = [&](int kb, int i, s16x8 a) __attribute__((always_inline)) {
+            const int st = i / DB, db = i % DB;
+            dq[db] = M::run(a, sb[2 * kb + st], dq[db]);
+        };
+        constexpr int EPB = 16 / (2 * KS), EPC = 16 / (2 * DB);   // elements per MFMA step in B and in C
+
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s[kb][i] = 0.f; dp[kb][i] = 0.f; }
+        stream(IC<2 * KS>{},                                                                       // A
+               [&](int i) __attribute__((always_inline)) -> s16x8 { return row_frag(0, i); },
+               [&](int i, s16x8 a) __attribute__((always_inline)) { row_mma(0, i, a); }, nothing);
+        stream(IC<2 * KS>{},                                                                       // B
+               [&](int i) __attribute__((always_inline)) -> s16x8 { return row_frag(1, i); },
+               [&](int i, s16x8 a) __attribute__((always_inline)) { row_mma(1, i, a); },
+               [&](int i) __attribute__((always_inline)) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const s16x8 a = *reinterpret_cast<const s16x8*>(Kb + img_off<D>(32 * kb + r, 2 * ks + h));
-                s[kb] = M::run(a, qf[ks], s[kb]);
-            }
+                   for (int e = 0; e < EPB; ++e) pds(0, EPB * i + e);
+               });
+        finish(0);
+        stream(IC<2 * DB>{},                                                                       // C
+               [&](int i) __attribute__((always_inline)) -> s16x8 { return tr_frag(0, i); },
+               [&](int i, s16x8 a) __attribute__((always_inline)) { tr_mma(0, i, a); },
+               [&](int i) __attribute__((always_inline)) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const s16x8 a = *reinterpret_cast<const s16x8*>(Vb + img_off<D>(32 * kb + r, 2 * ks + h));
-                dp[kb] = M::run(a, dof[ks], dp[kb]);
-            }
-        }
+                   for (int e = 0; e < EPC; ++e) pds(1, EPC * i + e);
+               });
+        finish(1);
+        stream(IC<2 * DB>{},                                                                       // D
+               [&](int i) __attribute__((always_inline)) -> s16x8 { return tr_frag(1, i); },
+               [&](int i, s16x8 a) __attribute__((always_inline)) { tr_mma(1, i, a); }, nothing);
 
-        // ---- dS^T = P^T o (dP^T - delta), P recomputed from the saved row statistic
-        const bool edge = kv0 + kTile > N || (CAUSAL && kv0 + kTile - 1 > q0 + 32 * (wave));
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], sl2, -lse2));
-                if (edge) {
-                    const int key = kv0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (key >= N || (CAUSAL && key > qrow)) p = 0.f;
-                }
-                s[kb][i] = p * (dp[kb][i] - delta);
-            }
-
-        // ---- dQ^T += K^T dS^T : 4 k-steps of 16 keys x DB row blocks
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                vec8 pb;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pb[j] = (T)s[kb][8 * st + j];
-                const int r0 = 32 * kb + 16 * st + 4 * h + tq;
-#pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const int ch = 4 * db + 2 * tg1 + (tp >> 1);
-                    const s16x4 lo = lds_read_tr(Kb + img_off<D>(r0, ch) + 8 * (tp & 1));
-                    const s16x4 hi = lds_read_tr(Kb + img_off<D>(r0 + 8, ch) + 8 * (tp & 1));
-                    s16x8 a;
-                    a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
-                    a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
-                    dq[db] = M::run(a, pb, dq[db]);
-                }
-            }
-
-        kst.write(lds + (buf ^ 1) * TILE_B, tid);
-        vst.write(lds + (2 + (buf ^ 1)) * TILE_B, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next tile are in
         __syncthreads();
     }
 
