@@ -24,6 +24,8 @@ collective on the timed path.  Rank 0 prints ONE JSON line:
                    my_attention(Q, K_t, V) at N=128 d=64 (config 1) and N=1024 d=64 (its largest
                    test shape), and the batched float32 flavour of the headline shape, against
                    104.8 TFLOP/s = 4 / (2/78.6 + 2/157.3), the two matrix rates in series
+  attention_backward  the backward (delta, dQ, dK/dV kernels) of the same shape: ms, TFLOP/s over 2.5x
+                   the forward's flops, and PyTorch's SDPA backward on the same tensors
   power_context    the same attention launch on all-ones operands, and the vendor bf16 GEMM
                    (torch.matmul -> hipBLASLt, 8192^3) on random and all-ones operands: the chip
                    lowers its clock under the power limit when operands are random, so these
@@ -192,6 +194,24 @@ def bench_softmax_1024(mfa, calls=1000):
             "reference_published_us": {"kernel_1": 110, "kernel_5": 71, "hardware": "NVIDIA T4"}}
 
 
+def bench_backward(mfa, B, H, N, d, dtype, scale):
+    """Forward + backward of the headline shape (untimed context of the headline number): the
+    backward's three kernels against 2.5x the forward's algorithmic flops, and PyTorch's own
+    scaled_dot_product_attention backward on the same tensors."""
+    torch.manual_seed(2)
+    q, k, v, do = (torch.randn(B, H, N, d, dtype=dtype, device="cuda") for _ in range(4))
+    out, lse = mfa.flash_attn_fwd(q, k, v, scale=scale, return_lse=True)
+    ms = _median_ms(lambda: mfa.flash_attn_bwd(do, q, k, v, out, lse, scale=scale), iters=10)
+    res = {"ms": round(ms, 3), "TFLOP/s_algorithmic": round(2.5 * attn_flops(B, H, N, d) / ms / 1e9, 1)}
+    qf, kf, vf = (x.detach().clone().requires_grad_(True) for x in (q, k, v))
+    o = torch.nn.functional.scaled_dot_product_attention(qf, kf, vf, scale=scale)
+    ms_t = _median_ms(lambda: torch.autograd.grad(o, (qf, kf, vf), do, retain_graph=True), iters=5, warm=2)
+    res["torch_sdpa_backward_ms"] = round(ms_t, 3)
+    del q, k, v, do, out, lse, qf, kf, vf, o
+    torch.cuda.empty_cache()
+    return res
+
+
 def cpu_baseline(B, H, N, d, scale, budget_s=12.0):
     """C oracle, float32 arithmetic, OpenMP: heads of the same workload until ~budget_s."""
     import numpy as np
@@ -304,6 +324,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras and not args.causal:
         result["power_context"] = power_context(mfa, B, H, N, d, dtype, scale)
         result["attention_f32"] = bench_attention_f32(mfa)
+        result["attention_backward"] = bench_backward(mfa, B, H, N, d, dtype, scale)
         result["softmax_sweep"] = bench_softmax_sweep(mfa)
         result["softmax_1024"] = bench_softmax_1024(mfa)
         result["cpu_baseline"] = cpu_baseline(B, H, N, d, scale)
