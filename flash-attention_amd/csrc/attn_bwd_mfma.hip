@@ -115,8 +115,8 @@ attn_bwd_dq_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* 
     // each lane's source chunk; rows past N read as zero through the buffer bounds check.
     constexpr int CPR = D / 8, LPT = kTile * CPR / THREADS, SUB_B = 16 * D;
     const unsigned head_bytes = (unsigned)N * D * 2;
-    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, head_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, head_bytes, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, head_bytes, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, head_bytes, 0x00020000);
     int st_goff[LPT];
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
@@ -327,10 +327,10 @@ attn_bwd_dkv_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T*
     // as zero through the buffer bounds check (and are masked as edge rows).
     constexpr int CPR = D / 8, LPT = kTile * CPR / THREADS;
     const unsigned head_bytes = (unsigned)N * D * 2;
-    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc((void*)Qh, 0, head_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)dOh, 0, head_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)lseh, 0, (unsigned)N * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)delh, 0, (unsigned)N * 4, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc((void*)Qh, 0, head_bytes, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)dOh, 0, head_bytes, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)lseh, 0, (unsigned)N * 4, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)delh, 0, (unsigned)N * 4, 0x00020000);
     int st_goff[LPT];
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {

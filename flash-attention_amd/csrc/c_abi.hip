@@ -31,6 +31,7 @@ int check_launch(const char* what) {
 // implemented in the kernel translation units
 int softmax_f32(const float* in, float* out, int64_t h, int64_t w, hipStream_t s);
 int softmax_rows(const void* in, void* out, int64_t h, int64_t w, int dtype, hipStream_t s);
+int matmul_f32(const float* a, const float* b, float* c, int64_t m, int64_t k, int64_t n, hipStream_t s);
 int attn_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse,
                  int64_t heads, int64_t N, int64_t d, int64_t k_key_stride, int64_t k_d_stride,
                  float scale, bool causal, hipStream_t s);
@@ -132,6 +133,10 @@ int myfa_attn_bwd_bhnd(const void* q, const void* k, const void* v, const void* 
         return fail(MYFA_E_INVALID, "attention backward: tensors must be 16-byte aligned");
     return attn_bwd_mfma(q, k, v, o, lse, dout, dq, dk, dv, delta_ws, B * H, N, d, scale, dtype,
                          (flags & MYFA_ATTN_CAUSAL) != 0, static_cast<hipStream_t>(stream));
+}
+
+int myfa_matmul_f32(const float* a, const float* b, float* c, int64_t m, int64_t k, int64_t n, void* stream) {
+    return matmul_f32(a, b, c, m, k, n, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -190,11 +190,11 @@ def flash_attn_func(q, k, v, scale=1.0, causal=False):
 
 
 # ---- the matmul trio ---------------------------------------------------------
-# Not on the softmax/attention path.  The reference's 16x16-tile kernel
-# (csrc/my_flash_attn/matmul.cu:22-50) and its cuBLAS wrapper (csrc/api.cpp:68-105)
-# are kept as names with the reference's checks; the product itself is
-# torch.matmul, i.e. the vendor GEMM of this platform, as the reference's
-# my_matmul_cublas is the vendor GEMM of its platform.
+# Not on the softmax/attention path.  my_matmul / my_matmul_out run the library's own
+# float32 MFMA kernel, as the reference's run its own 16x16-tile kernel
+# (csrc/my_flash_attn/matmul.cu:22-50, csrc/api.cpp:13-66); my_matmul_cublas
+# (csrc/api.cpp:68-105) is the vendor GEMM of this platform (torch.matmul), as the
+# reference's is the vendor GEMM of its platform.
 
 def _matmul_checks(A, B):
     _check_input(A, "A"); _check_input(B, "B")
@@ -202,9 +202,18 @@ def _matmul_checks(A, B):
         raise RuntimeError("Size mismatch!")
 
 
+def _matmul_into(out, A, B):
+    _check_float(A, "A"); _check_float(B, "B"); _check_float(out, "out")
+    m, k = A.shape
+    n = B.shape[1]
+    with torch.cuda.device(A.device):
+        _lib.check(_lib.lib.myfa_matmul_f32(A.data_ptr(), B.data_ptr(), out.data_ptr(), m, k, n, _stream()))
+    return out
+
+
 def my_matmul(A, B):
     _matmul_checks(A, B)
-    return torch.matmul(A, B)
+    return _matmul_into(torch.empty((A.shape[0], B.shape[1]), dtype=A.dtype, device=A.device), A, B)
 
 
 def my_matmul_cublas(A, B):
@@ -219,5 +228,4 @@ def my_matmul_out(out, A, B):
         raise RuntimeError("Size mismatch!")
     if not (out.dtype == A.dtype == B.dtype):
         raise RuntimeError("Scalar type mismatch!")
-    torch.matmul(A, B, out=out)
-    return out
+    return _matmul_into(out, A, B)

@@ -24,6 +24,7 @@ EXPORTS = (
     "myfa_attn_fwd_bhnd",
     "myfa_attn_fwd_bhnd_ex",
     "myfa_attn_bwd_bhnd",
+    "myfa_matmul_f32",
 )
 
 
@@ -53,6 +54,8 @@ def _load():
     lib.myfa_attn_fwd_bhnd_ex.restype = ci
     lib.myfa_attn_bwd_bhnd.argtypes = [vp] * 10 + [i64, i64, i64, i64, f32, ci, ci, vp]
     lib.myfa_attn_bwd_bhnd.restype = ci
+    lib.myfa_matmul_f32.argtypes = [vp, vp, vp, i64, i64, i64, vp]
+    lib.myfa_matmul_f32.restype = ci
     got = lib.myfa_abi_version()
     if got != ABI_VERSION:
         raise ImportError(f"{LIB_PATH}: ABI version {got}, this package expects {ABI_VERSION}; rebuild")

@@ -145,6 +145,14 @@ int myfa_attn_bwd_bhnd(const void* q, const void* k, const void* v, const void* 
                        int64_t B, int64_t H, int64_t N, int64_t d,
                        float scale, int dtype, int flags, void* stream);
 
+/*
+ * c[m, n] = a[m, k] . b[k, n], float32, dense row-major.  Replaces the reference's
+ * own tiled kernel behind my_matmul / my_matmul_out (launch_matmul_kernel,
+ * csrc/my_flash_attn/matmul.cu:22-62, called from csrc/api.cpp:13-66).  Every
+ * element of c is written (the reference zero-fills first, api.cpp:46).
+ */
+int myfa_matmul_f32(const float* a, const float* b, float* c, int64_t m, int64_t k, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,7 +75,8 @@ def test_my_attention_errors(mfa):
 
 def test_matmul_trio(mfa):
     # reference shapes, tests/test_flash_attn.py:106-130
-    for (h, k, w) in [(2, 2, 20), (20, 2, 2), (3, 7, 11), (1000, 10, 10), (10, 10, 1000), (999, 999, 999)]:
+    for (h, k, w) in [(2, 2, 20), (20, 2, 2), (3, 7, 11), (1024, 1024, 1024), (1000, 10, 10), (10, 10, 1000),
+                      (999, 999, 999), (1, 1, 1), (65, 17, 129), (64, 16, 64), (300, 1, 5)]:
         torch.manual_seed(1)
         a, b = torch.randn(h, k, device="cuda"), torch.randn(k, w, device="cuda")
         ref = (a.double() @ b.double()).float()
