@@ -36,13 +36,14 @@ def head_checksums(o):
     return torch.stack([f.sum(dim=2)[0], (f * f).sum(dim=2)[0]], dim=1)
 
 
-def gather_head_checksums(o, total_heads, rank, world, group=None):
+def gather_head_checksums(o, total_heads, rank, world, group=None, force=False):
     """All-gathers the per-head checksums of every rank's shard into one (total_heads, 2)
-    tensor in head order (equal on all ranks).  Verification only; not on the timed path."""
+    tensor in head order (equal on all ranks).  Verification only; not on the timed path.
+    `force` runs the collective even in a world of one (rehearsal)."""
     mine = head_checksums(o)
     full = torch.zeros((total_heads, 2), dtype=torch.float64, device=o.device)
     s, e = head_range(total_heads, rank, world)
     full[s:e] = mine
-    if world > 1:
+    if world > 1 or force:
         dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)   # disjoint rows: sum == gather
     return full
