@@ -26,6 +26,9 @@ SOURCES = ["c_abi.hip", "softmax_rows.hip", "attn_fwd_f32.hip", "attn_fwd_mfma.h
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + INCLUDE, "-I" + CSRC,
          "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
+# The backward kernels place every vector instruction by hand between MFMAs; the SLP vectoriser
+# regroups them into packed float32 pairs with register shuffles around them.
+PER_SOURCE_FLAGS = {"attn_bwd_mfma.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -47,7 +50,7 @@ def _compile(src, extra):
     stamp = max(os.path.getmtime(path), _newest_header(), os.path.getmtime(__file__))
     if os.path.exists(obj) and os.path.getmtime(obj) >= stamp:
         return obj, False
-    subprocess.check_call([_hipcc(), *FLAGS, *extra, "-c", path, "-o", obj])
+    subprocess.check_call([_hipcc(), *FLAGS, *PER_SOURCE_FLAGS.get(src, []), *extra, "-c", path, "-o", obj])
     return obj, True
 
 

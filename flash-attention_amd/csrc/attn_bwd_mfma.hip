@@ -33,13 +33,13 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float kLog2e = 1.4426950408889634f;
-template <int V> struct IC { static constexpr int value = V; };
 
 constexpr int kTile = 64;            // rows of a streamed tile (keys in dQ, queries in dK/dV)
 
 // ---------------------------------------------------------------- delta = rowsum(dO o O)
-// (and the row statistic in base 2, lse * log2(e), next to it: the two per-row scalars the
-// other kernels consume, in one workspace of 2 * rows floats: [delta | lse2])
+// (stored NEGATED, so that the dK/dV kernel can start its dP accumulators from it, and the row
+// statistic in base 2, lse * log2(e), next to it: the two per-row scalars the other kernels
+// consume, in one workspace of 2 * rows floats: [-delta | lse2])
 template <typename T, int D>
 __global__ void __launch_bounds__(256)
 attn_bwd_delta_kernel(const T* __restrict__ Og, const T* __restrict__ dOg, const float* __restrict__ LSEg,
@@ -58,7 +58,7 @@ attn_bwd_delta_kernel(const T* __restrict__ Og, const T* __restrict__ dOg, const
 #pragma unroll
     for (int m = 1; m < CPR; m <<= 1) acc += __shfl_xor(acc, m);
     if (row < rows && ch == 0) {
-        DELg[row] = acc;
+        DELg[row] = -acc;
         DELg[rows + row] = LSEg[row] * kLog2e;
     }
 }
@@ -102,7 +102,7 @@ attn_bwd_dq_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* 
         dof[ks] = *reinterpret_cast<const vec8*>(dOg + hoff + (size_t)qrow_c * D + 16 * ks + 8 * h);
     }
     const float lse2 = LSEg[(size_t)head * N + qrow_c] * kLog2e;
-    const float delta = DELg[(size_t)head * N + qrow_c];
+    const float ndelta = DELg[(size_t)head * N + qrow_c];      // -delta
     const float sl2 = scale * kLog2e;
 
     f32x16 dq[DB];
@@ -192,7 +192,7 @@ attn_bwd_dq_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* 
         vec8 sb[4];
         auto pds = [&](int kb, int i) __attribute__((always_inline)) {
             const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], sl2, -lse2));
-            s[kb][i] = p * (dp[kb][i] - delta);
+            s[kb][i] = p * (dp[kb][i] + ndelta);
         };
         auto finish = [&](int kb) __attribute__((always_inline)) {
             if (edge) {
@@ -279,6 +279,82 @@ attn_bwd_dq_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* 
 }
 
 // ---------------------------------------------------------------- dK, dV
+// The vector work of one tile of the dK/dV kernel, planned at compile time.
+//
+// One wave per SIMD means nothing but the wave's own MFMAs can cover its vector instructions, and
+// the wave issues ONE instruction at a time: everything that is not an MFMA has to fit, in issue
+// slots, between MFMAs that each keep the matrix core busy for 32 cycles.  A tile is 8 KS MFMA
+// steps (g = 0 .. 8 KS - 1):
+//     A  [0, 2KS)    S0 = Q0 K^T (KS steps), dP0 = dO0 V^T (KS)        block 0 = queries 0..31
+//     B  [2KS, 4KS)  S1, dP1                                            block 1 = queries 32..63
+//     C  [4KS, 6KS)  dV += dO0^T P0, dK += Q0^T dS0, alternating; its first half takes elements
+//                    0..7 of the block's accumulators, its second half elements 8..15
+//     D  [6KS, 8KS)  the same for block 1
+// and per accumulator element e of a block the vector work is
+//     kind 0   t = s * scale*log2e - lse2          (needs S: two steps behind its last MFMA)
+//     kind 1   p = exp2(t)
+//     kind 2   ds = p * dp                         (needs dP, which started from -delta)
+//     kind 3   P pair (2e, 2e+1) -> 16 bit         kind 4   dS pair -> 16 bit
+// plan_dkv() deals these 128 operations onto the steps: earliest deadline first, an operation
+// never in the same step as the one it depends on, at most `cap` cycles of issue per step.
+struct DkvOp { int blk, kind, e; };
+template <int KS> struct DkvPlan {
+    static constexpr int NSTEP = 8 * KS, NOPS = 128;
+    DkvOp op[NOPS] = {};
+    int start[NSTEP + 1] = {};
+    bool ok = false;
+};
+template <int KS>
+constexpr DkvPlan<KS> plan_dkv(int cap) {
+    constexpr int cost[5] = {5, 9, 5, 8, 8};
+    DkvPlan<KS> p{};
+    int at[2][5][16] = {};
+    for (int b = 0; b < 2; ++b)
+        for (int k = 0; k < 5; ++k)
+            for (int e = 0; e < 16; ++e) at[b][k][e] = -1;
+    int n = 0;
+    bool late = false;
+    for (int g = 0; g < p.NSTEP; ++g) {
+        p.start[g] = n;
+        int budget = cap;
+        while (true) {
+            int bb = -1, bk = -1, be = -1, bdl = 1 << 30;
+            for (int b = 0; b < 2; ++b) {
+                const int s_rdy = (2 * b + 1) * KS + 1, dp_rdy = (2 * b + 2) * KS + 1;
+                for (int k = 4; k >= 0; --k)
+                    for (int e = 0; e < (k < 3 ? 16 : 8); ++e) {
+                        if (at[b][k][e] >= 0) continue;
+                        bool rdy = false;
+                        if (k == 0) rdy = g >= s_rdy;
+                        if (k == 1) rdy = at[b][0][e] >= 0 && at[b][0][e] < g;
+                        if (k == 2) rdy = g >= dp_rdy && at[b][1][e] >= 0 && at[b][1][e] < g;
+                        if (k == 3) rdy = at[b][1][2 * e] >= 0 && at[b][1][2 * e] < g && at[b][1][2 * e + 1] >= 0 && at[b][1][2 * e + 1] < g;
+                        if (k == 4) rdy = at[b][2][2 * e] >= 0 && at[b][2][2 * e] < g && at[b][2][2 * e + 1] >= 0 && at[b][2][2 * e + 1] < g;
+                        if (!rdy) continue;
+                        const int e0 = k < 3 ? e : 2 * e;
+                        const int dl = (4 + 2 * b) * KS + (e0 >= 8 ? KS : 0) - 1;     // last step it may run behind
+                        if (dl < bdl) { bdl = dl; bb = b; bk = k; be = e; }           // (ties: later kind, lower element)
+                    }
+            }
+            if (bb < 0 || cost[bk] > budget) break;
+            budget -= cost[bk];
+            at[bb][bk][be] = g;
+            p.op[n++] = DkvOp{bb, bk, be};
+            if (g > bdl) late = true;
+        }
+    }
+    p.start[p.NSTEP] = n;
+    p.ok = n == p.NOPS && !late;
+    return p;
+}
+// the smallest issue budget per step (in cycles) that meets every deadline
+template <int KS, int CAP = 16, bool OK = plan_dkv<KS>(CAP).ok> struct DkvPlanFor;
+template <int KS, int CAP> struct DkvPlanFor<KS, CAP, true> {
+    static constexpr int cap = CAP;
+    static constexpr DkvPlan<KS> plan = plan_dkv<KS>(CAP);
+};
+template <int KS, int CAP> struct DkvPlanFor<KS, CAP, false> : DkvPlanFor<KS, CAP + 2> {};
+
 template <typename T, int D, bool CAUSAL>
 __global__ void __launch_bounds__(256, 1)
 attn_bwd_dkv_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* __restrict__ Vg,
@@ -364,9 +440,17 @@ attn_bwd_dkv_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T*
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dk[db][i] = 0.f; dv[db][i] = 0.f; }
 
+    // The tiles of queries this key block sees, in the order they are taken: tiles that need the
+    // mask first (the ragged last tile, then under the causal mask the two tiles that straddle the
+    // diagonal; every tile if the key block itself is ragged), then the others.  The two kinds
+    // run in two loops so that the common one carries no mask code.
     const int T_all = (N + kTile - 1) / kTile;
     const int t0 = CAUSAL ? k0 / kTile : 0;        // causal: queries before the block's first key see none of it
-    fetch_tile(t0, 0);
+    const int n_tiles = T_all - t0;
+    const int has_tail = (N % kTile) != 0 ? 1 : 0;
+    const int n_edge = k0 + BK > N ? n_tiles : has_tail + (CAUSAL ? min(2, n_tiles - has_tail) : 0);
+    auto tile_of = [=](int j) __attribute__((always_inline)) { return (has_tail && j == 0) ? T_all - 1 : t0 + j - has_tail; };
+    fetch_tile(tile_of(0), 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -381,142 +465,121 @@ attn_bwd_dkv_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T*
         rbase[e] = SUB_B * (r >> 3) + 64 * (r & 7) + 16 * ((2 * e + h) ^ ((r >> 2) & 3));
         tbase[e] = 64 * (4 * h + tq) + 16 * ((2 * tg1 + (tp >> 1)) ^ (2 * e + h)) + 8 * (tp & 1) + SUB_B * e;
     }
-    // An MFMA sequence as one software-pipelined stream: the LDS fragment of MFMA i + FW is
-    // requested when MFMA i issues (with one wave per SIMD nothing else hides the LDS latency),
-    // and the order is pinned so that the scheduler does not move each read back to its use.
-    constexpr int FW = 8;
-    // `after(i)` runs behind MFMA i: vector work placed there executes in the MFMA's shadow.
-    auto stream = [&](auto n_, auto&& frag, auto&& mma, auto&& after) __attribute__((always_inline)) {
-        constexpr int NFR = decltype(n_)::value;
-        s16x8 win[FW];
-#pragma unroll
-        for (int i = 0; i < FW && i < NFR; ++i) win[i] = frag(i);
-#pragma unroll
-        for (int i = 0; i < NFR; ++i) {
-            const s16x8 a = win[i % FW];
-            mma(i, a);
-            if (i + FW < NFR) win[i % FW] = frag(i + FW);
-            after(i);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    auto nothing = [](int) __attribute__((always_inline)) {};
+    using Plan = DkvPlanFor<KS>;
+    static_assert(Plan::plan.ok && 4 * DB == 2 * KS, "every vector operation placed before its deadline");
+    constexpr int NSTEP = 8 * KS, FW = 8;
 
-    for (int t = t0; t < T_all; ++t) {
-        const int buf = (t - t0) & 1;
-        const int qt0 = t * kTile;
-        // the next tile into the other buffer (last read before the previous barrier); unconditional,
-        // a tile past the end reads zeros.  It has the whole tile's compute to land.
-        fetch_tile(t + 1, buf ^ 1);
+    auto run_tiles = [&](int j0, int j1, auto edge_) __attribute__((always_inline)) {
+    for (int j = j0; j < j1; ++j) {
+        const int buf = j & 1;
+        const int qt0 = tile_of(j) * kTile;
+        // the next tile into the other buffer (last read before the previous barrier); unconditional
+        // (behind the last tile: a tile nobody reads).  It has the whole tile's compute to land.
+        fetch_tile(tile_of(j + 1), buf ^ 1);
         const char* Qb = lds + buf * TILE_B;
         const char* dOb = lds + (2 + buf) * TILE_B;
         const float* lse2b = stat + buf * 2 * kTile;
-        const float* delb = lse2b + kTile;
+        const float* ndelb = lse2b + kTile;
 
-        // The tile's 64 queries are two blocks of 32, and the work of the two blocks is staggered so
-        // that the vector part of one block runs in the shadow of the other block's MFMAs:
-        //   A  S0, dP0                          (MFMA only)
-        //   B  S1, dP1      with P0, dS0        (one or two elements behind every MFMA)
-        //   C  dV, dK += block 0   with P1, dS1
-        //   D  dV, dK += block 1
-        // S = Q K^T and dP = dO V^T put the key on the lane; accumulator register i of block qb
-        // is query 32qb + (i & 3) + 8 (i >> 2) + 4h, so the rows' lse and delta come as four
-        // broadcast float4 reads per block.
-        const bool edge = qt0 + kTile > N || k0 + BK > N || (CAUSAL && k0 + BK - 1 > qt0);
+        // S = Q K^T and dP = dO V^T put the key on the lane; accumulator register i of block qb is
+        // query 32qb + (i & 3) + 8 (i >> 2) + 4h, so the rows' lse2 come as four broadcast float4
+        // reads per block, and four more start the dP accumulators at -delta.  S and dP live in
+        // VECTOR registers (acc_v / first_v), dK and dV in accumulator registers.
         f32x16 s[2], dp[2];
-        f32x4 l4[2][4], d4[2][4];
+        f32x4 l4[2][4];
         vec8 pb[4], sb[4];
-        auto load_stat = [&](int qb) __attribute__((always_inline)) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                l4[qb][g] = *reinterpret_cast<const f32x4*>(lse2b + 32 * qb + 8 * g + 4 * h);
-                d4[qb][g] = *reinterpret_cast<const f32x4*>(delb + 32 * qb + 8 * g + 4 * h);
-            }
-        };
-        auto pds = [&](int qb, int i) __attribute__((always_inline)) {     // P and dS of one element
-            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][i], sl2, -l4[qb][i >> 2][i & 3]));
-            s[qb][i] = p;
-            dp[qb][i] = p * (dp[qb][i] - d4[qb][i >> 2][i & 3]);
-        };
-        auto finish = [&](int qb) __attribute__((always_inline)) {         // edge mask, then 16-bit operands
-            if (edge) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int qglob = qt0 + 32 * qb + 8 * (i >> 2) + 4 * h + (i & 3);
-                    if (qglob >= N || krow >= N || (CAUSAL && krow > qglob)) { s[qb][i] = 0.f; dp[qb][i] = 0.f; }
-                }
-            }
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    pb[2 * qb + st][j] = (T)s[qb][8 * st + j];
-                    sb[2 * qb + st][j] = (T)dp[qb][8 * st + j];
-                }
-        };
-        // fragment i of block qb's first half: group i / KS: 0 = Q rows for S, 1 = dO rows for dP
-        auto row_frag = [&](int qb, int i) __attribute__((always_inline)) -> s16x8 {
-            const int which = i / KS, ks = i % KS;
-            const char* tile = which ? dOb : Qb;
-            return *reinterpret_cast<const s16x8*>(tile + rbase[ks & 1] + SUB_B * 4 * qb + 512 * (ks >> 1));
-        };
-        auto row_mma = [&](int qb, int i, s16x8 a) __attribute__((always_inline)) {
-            const int which = i / KS, ks = i % KS;
-            if (which) dp[qb] = M::run(a, vf[ks], dp[qb]);
-            else s[qb] = M::run(a, kf[ks], s[qb]);
-        };
-        // fragment i of block qb's second half: k-step st = i / (2 DB), then (db, which): 0 = dO^T for dV, 1 = Q^T for dK
-        auto tr_frag = [&](int qb, int i) __attribute__((always_inline)) -> s16x8 {
-            const int st = i / (2 * DB), db = (i / 2) % DB, which = i & 1;
-            const char* tile = which ? Qb : dOb;
-            const int imm = SUB_B * 2 * (2 * qb + st) + 512 * db;
-            const s16x4 lo = lds_read_tr(tile + tbase[0] + imm);
-            const s16x4 hi = lds_read_tr(tile + tbase[1] + imm);
-            s16x8 a;
-            a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
-            a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
-            return a;
-        };
-        auto tr_mma = [&](int qb, int i, s16x8 a) __attribute__((always_inline)) {
-            const int st = i / (2 * DB), db = (i / 2) % DB, which = i & 1;
-            if (which) dk[db] = M::run(a, sb[2 * qb + st], dk[db]);
-            else dv[db] = M::run(a, pb[2 * qb + st], dv[db]);
-        };
-        constexpr int EPM = 16 / (2 * KS);            // elements per MFMA step (2 KS = 4 DB steps per half)
-        static_assert(2 * KS == 4 * DB && EPM * 2 * KS == 16, "phases of equal length");
-
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { s[qb][i] = 0.f; dp[qb][i] = 0.f; }
-        load_stat(0);
-        stream(IC<2 * KS>{},                                                                       // A
-               [&](int i) __attribute__((always_inline)) -> s16x8 { return row_frag(0, i); },
-               [&](int i, s16x8 a) __attribute__((always_inline)) { row_mma(0, i, a); }, nothing);
-        load_stat(1);
-        stream(IC<2 * KS>{},                                                                       // B
-               [&](int i) __attribute__((always_inline)) -> s16x8 { return row_frag(1, i); },
-               [&](int i, s16x8 a) __attribute__((always_inline)) { row_mma(1, i, a); },
-               [&](int i) __attribute__((always_inline)) {
-#pragma unroll
-                   for (int e = 0; e < EPM; ++e) pds(0, EPM * i + e);
-               });
-        finish(0);
-        stream(IC<4 * DB>{},                                                                       // C
-               [&](int i) __attribute__((always_inline)) -> s16x8 { return tr_frag(0, i); },
-               [&](int i, s16x8 a) __attribute__((always_inline)) { tr_mma(0, i, a); },
-               [&](int i) __attribute__((always_inline)) {
-#pragma unroll
-                   for (int e = 0; e < EPM; ++e) pds(1, EPM * i + e);
-               });
-        finish(1);
-        stream(IC<4 * DB>{},                                                                       // D
-               [&](int i) __attribute__((always_inline)) -> s16x8 { return tr_frag(1, i); },
-               [&](int i, s16x8 a) __attribute__((always_inline)) { tr_mma(1, i, a); }, nothing);
+            for (int g = 0; g < 4; ++g) {
+                l4[qb][g] = *reinterpret_cast<const f32x4*>(lse2b + 32 * qb + 8 * g + 4 * h);
+                const f32x4 nd = *reinterpret_cast<const f32x4*>(ndelb + 32 * qb + 8 * g + 4 * h);
+                dp[qb][4 * g] = nd[0]; dp[qb][4 * g + 1] = nd[1]; dp[qb][4 * g + 2] = nd[2]; dp[qb][4 * g + 3] = nd[3];
+            }
+
+        // pairs (query, key) outside the problem or above the diagonal: element c = 32qb + 8(i>>2) + (i&3)
+        // of this lane is masked iff c >= c_hi or c < c_lo
+        const int c_hi = krow < N ? N - (qt0 + 4 * h) : -1;
+        const int c_lo = CAUSAL ? krow - (qt0 + 4 * h) : -(1 << 30);
+
+        // LDS fragment of step g: A, B: a row read of Q (S) or dO (dP); C, D: a transposing read of
+        // dO (dV) or Q (dK), k-step st = i / (2 DB), then (db, which)
+        auto frag = [&](auto gc) __attribute__((always_inline)) -> s16x8 {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g < 4 * KS) {
+                constexpr int qb = g / (2 * KS), which = (g / KS) & 1, ks = g % KS;
+                const char* tile = which ? dOb : Qb;
+                return *reinterpret_cast<const s16x8*>(tile + rbase[ks & 1] + SUB_B * 4 * qb + 512 * (ks >> 1));
+            } else {
+                constexpr int qb = (g - 4 * KS) / (2 * KS), i = g % (2 * KS);
+                constexpr int st = i / (2 * DB), db = (i / 2) % DB, which = i & 1;
+                const char* tile = which ? Qb : dOb;
+                constexpr int imm = SUB_B * 2 * (2 * qb + st) + 512 * db;
+                const s16x4 lo = lds_read_tr(tile + tbase[0] + imm);
+                const s16x4 hi = lds_read_tr(tile + tbase[1] + imm);
+                s16x8 a;
+                a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
+                a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
+                return a;
+            }
+        };
+        auto mma = [&](auto gc, s16x8 a) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g < 4 * KS) {
+                constexpr int qb = g / (2 * KS), which = (g / KS) & 1, ks = g % KS;
+                if constexpr (which) M::acc_v(a, vf[ks], dp[qb]);
+                else if constexpr (ks == 0) M::first_v(a, kf[0], s[qb]);
+                else M::acc_v(a, kf[ks], s[qb]);
+            } else {
+                constexpr int qb = (g - 4 * KS) / (2 * KS), i = g % (2 * KS);
+                constexpr int st = i / (2 * DB), db = (i / 2) % DB, which = i & 1;
+                if constexpr (which) dk[db] = M::run(a, sb[2 * qb + st], dk[db]);
+                else dv[db] = M::run(a, pb[2 * qb + st], dv[db]);
+            }
+        };
+        // one planned vector operation
+        auto vop = [&](auto edge_, auto op_) __attribute__((always_inline)) {
+            constexpr bool EDGE = decltype(edge_)::value != 0;
+            constexpr int o = decltype(op_)::value;
+            constexpr int qb = Plan::plan.op[o].blk, kind = Plan::plan.op[o].kind, e = Plan::plan.op[o].e;
+            if constexpr (kind == 0) {
+                s[qb][e] = __builtin_fmaf(s[qb][e], sl2, -l4[qb][e >> 2][e & 3]);
+            } else if constexpr (kind == 1) {
+                const float pe = __builtin_amdgcn_exp2f(s[qb][e]);
+                constexpr int c = 32 * qb + 8 * (e >> 2) + (e & 3);
+                if constexpr (EDGE) s[qb][e] = (c >= c_hi || c < c_lo) ? 0.f : pe;
+                else s[qb][e] = pe;
+            } else if constexpr (kind == 2) {
+                dp[qb][e] *= s[qb][e];
+            } else if constexpr (kind == 3) {
+                pb[2 * qb + (e >> 2)][(2 * e) & 7] = (T)s[qb][2 * e];
+                pb[2 * qb + (e >> 2)][((2 * e) & 7) + 1] = (T)s[qb][2 * e + 1];
+            } else {
+                sb[2 * qb + (e >> 2)][(2 * e) & 7] = (T)dp[qb][2 * e];
+                sb[2 * qb + (e >> 2)][((2 * e) & 7) + 1] = (T)dp[qb][2 * e + 1];
+            }
+        };
+        // The tile as ONE software-pipelined stream of 8 KS MFMAs: the LDS fragment of MFMA g + FW is
+        // requested when MFMA g issues (nothing else hides the LDS latency), the planned vector
+        // operations of step g follow in that MFMA's shadow, and the order is pinned.
+        s16x8 win[FW];
+        static_for<FW>([&](auto ic) __attribute__((always_inline)) { win[decltype(ic)::value] = frag(ic); });
+        static_for<NSTEP>([&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;
+            const s16x8 a = win[g % FW];
+            mma(gc, a);
+            if constexpr (g + FW < NSTEP) win[g % FW] = frag(IC<g + FW>{});
+            constexpr int o0 = Plan::plan.start[g], o1 = Plan::plan.start[g + 1];
+            static_for<o1 - o0>([&](auto oc) __attribute__((always_inline)) { vop(edge_, IC<o0 + decltype(oc)::value>{}); });
+            __builtin_amdgcn_sched_barrier(0);
+        });
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next tile are in
         __syncthreads();
     }
+    };
+    run_tiles(0, n_edge, IC<1>{});
+    run_tiles(n_edge, n_tiles, IC<0>{});
 
     if (krow < N) {
         T* krow_p = dKg + hoff + (size_t)krow * D;

@@ -285,7 +285,6 @@ __device__ __forceinline__ unsigned long long stamp() {
     return t;
 }
 
-template <int V> struct IC { static constexpr int value = V; };
 
 
 template <typename T, int D, bool STAMP = false, bool CAUSAL = false>

@@ -3,6 +3,8 @@
 // lane-half exchanges and the LDS tile image.
 #ifndef MYFA_ATTN_MFMA_COMMON_H_
 #define MYFA_ATTN_MFMA_COMMON_H_
+#include <utility>
+
 #include "myfa_common.h"
 
 namespace myfa {
@@ -17,12 +19,31 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
+// run():   the compiler's MFMA; it places the accumulator (vector or accumulator register file)
+//          and keeps the MFMA's result-latency rules itself.
+// acc_v(), first_v(): the same instruction written out with the accumulator pinned to VECTOR
+//          registers (c += a b, and c = a b).  For kernels that run one wave per SIMD: there the
+//          compiler plans every MFMA result into accumulator registers and then moves tiles that
+//          vector instructions consume back and forth.  The compiler does not see an MFMA in
+//          these, so the caller keeps the result-latency rule: no vector instruction may read or
+//          write c until two further MFMAs have been issued behind the last one that wrote it
+//          (8 passes = 32 cycles each; the rule asks for 11 issue slots of 4 cycles).
 template <typename T> struct Mma;
 template <> struct Mma<__bf16> {
     using vec8 = bf16x8;
     using vec4 = bf16x4;
     static __device__ __forceinline__ f32x16 run(s16x8 a, vec8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vec8, a), b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void acc_v([[maybe_unused]] s16x8 a, [[maybe_unused]] vec8 b, [[maybe_unused]] f32x16& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+#endif
+    }
+    static __device__ __forceinline__ void first_v([[maybe_unused]] s16x8 a, [[maybe_unused]] vec8 b, [[maybe_unused]] f32x16& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+#endif
     }
 };
 template <> struct Mma<_Float16> {
@@ -31,7 +52,24 @@ template <> struct Mma<_Float16> {
     static __device__ __forceinline__ f32x16 run(s16x8 a, vec8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vec8, a), b, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ void acc_v([[maybe_unused]] s16x8 a, [[maybe_unused]] vec8 b, [[maybe_unused]] f32x16& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+#endif
+    }
+    static __device__ __forceinline__ void first_v([[maybe_unused]] s16x8 a, [[maybe_unused]] vec8 b, [[maybe_unused]] f32x16& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+#endif
+    }
 };
+
+// Compile-time loop: f(IC<0>{}), f(IC<1>{}), ..., f(IC<N-1>{}).
+template <int V> struct IC { static constexpr int value = V; };
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(IC<I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef __attribute__((address_space(3))) void lds_void;
