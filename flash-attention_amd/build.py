@@ -22,7 +22,7 @@ OBJ = os.path.join(CSRC, ".obj")
 PKG = os.path.join(HERE, "my_flash_attn_cuda")
 LIB = os.path.join(PKG, "libmyfa_gfx950.so")
 
-SOURCES = ["c_abi.hip", "softmax_rows.hip", "attn_fwd_f32.hip", "attn_fwd_mfma.hip", "attn_bwd_mfma.hip", "matmul_f32.hip"]
+SOURCES = ["c_abi.hip", "softmax_rows.hip", "softmax_strided.hip", "attn_fwd_f32.hip", "attn_fwd_mfma.hip", "attn_bwd_mfma.hip", "matmul_f32.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + INCLUDE, "-I" + CSRC,
          "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]

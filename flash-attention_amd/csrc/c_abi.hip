@@ -31,6 +31,7 @@ int check_launch(const char* what) {
 // implemented in the kernel translation units
 int softmax_f32(const float* in, float* out, int64_t h, int64_t w, hipStream_t s);
 int softmax_rows(const void* in, void* out, int64_t h, int64_t w, int dtype, hipStream_t s);
+int softmax_strided(const void* in, void* out, int64_t outer, int64_t len, int64_t inner, int dtype, hipStream_t s);
 int matmul_f32(const float* a, const float* b, float* c, int64_t m, int64_t k, int64_t n, hipStream_t s);
 int attn_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse,
                  int64_t heads, int64_t N, int64_t d, int64_t k_key_stride, int64_t k_d_stride,
@@ -71,6 +72,10 @@ int myfa_softmax_f32(const float* in, float* out, int64_t h, int64_t w, void* st
 
 int myfa_softmax(const void* in, void* out, int64_t h, int64_t w, int dtype, void* stream) {
     return softmax_rows(in, out, h, w, dtype, static_cast<hipStream_t>(stream));
+}
+
+int myfa_softmax_nd(const void* in, void* out, int64_t outer, int64_t len, int64_t inner, int dtype, void* stream) {
+    return softmax_strided(in, out, outer, len, inner, dtype, static_cast<hipStream_t>(stream));
 }
 
 int myfa_attn_fwd_f32(const float* q, const float* k_t, const float* v, float* o,

@@ -24,7 +24,7 @@ from . import _lib
 from ._lib import MYFA_BF16, MYFA_F16, MYFA_F32, device_info  # noqa: F401
 
 __all__ = ["my_softmax", "my_attention", "my_matmul", "my_matmul_cublas", "my_matmul_out",
-           "flash_attn_fwd", "device_info"]
+           "flash_attn_fwd", "flash_attn_bwd", "flash_attn_func", "softmax_rows", "softmax", "device_info"]
 
 _DTYPE_TAG = {torch.float32: MYFA_F32, torch.float16: MYFA_F16, torch.bfloat16: MYFA_BF16}
 
@@ -83,6 +83,31 @@ def softmax_rows(inp):
     out = torch.empty_like(inp)
     with torch.cuda.device(inp.device):
         _lib.check(_lib.lib.myfa_softmax(inp.data_ptr(), out.data_ptr(), h, w, _DTYPE_TAG[inp.dtype], _stream()))
+    return out
+
+
+def softmax(inp, dim=-1):
+    """torch.softmax(inp, dim) for a contiguous float32, float16 or bfloat16 tensor of any rank;
+    returns a new tensor of the same dtype.  New surface (the reference's my_softmax is rows of
+    a 2-D float32 matrix, csrc/api.cpp:110-166): the tensor is viewed as [outer, len, inner]
+    around `dim`, the last dimension goes to the row kernel, any other to the column kernels."""
+    _check_input(inp, "inp")
+    if inp.dtype not in _DTYPE_TAG:
+        raise RuntimeError(f"unsupported dtype {inp.dtype}")
+    if inp.dim() == 0:
+        raise RuntimeError("softmax expects a tensor with at least one dimension")
+    if not -inp.dim() <= dim < inp.dim():
+        raise IndexError(f"Dimension out of range (expected to be in range of [{-inp.dim()}, {inp.dim() - 1}], but got {dim})")
+    dim %= inp.dim()
+    outer = inner = 1
+    for n in inp.shape[:dim]:
+        outer *= n
+    for n in inp.shape[dim + 1:]:
+        inner *= n
+    out = torch.empty_like(inp)
+    with torch.cuda.device(inp.device):
+        _lib.check(_lib.lib.myfa_softmax_nd(inp.data_ptr(), out.data_ptr(), outer, inp.shape[dim], inner,
+                                            _DTYPE_TAG[inp.dtype], _stream()))
     return out
 
 

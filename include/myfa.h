@@ -81,6 +81,18 @@ int myfa_softmax_f32(const float* in, float* out, int64_t h, int64_t w, void* st
 int myfa_softmax(const void* in, void* out, int64_t h, int64_t w, int dtype, void* stream);
 
 /*
+ * Softmax along any one dimension of a dense tensor, viewed as [outer, len, inner]:
+ * out[o, :, i] = softmax(in[o, :, i]) -- torch.softmax(x, dim) with outer = product of the
+ * sizes before dim, len = size of dim, inner = product of the sizes after it.  inner == 1
+ * is myfa_softmax on an [outer, len] matrix.  Same element types and float32 arithmetic as
+ * myfa_softmax; in-place is allowed; any size 0 is a no-op.
+ * The reference has rows of a 2-D matrix only (csrc/api.cpp:110-166); this generalises
+ * that entry point to the other dimensions.
+ */
+int myfa_softmax_nd(const void* in, void* out, int64_t outer, int64_t len, int64_t inner,
+                    int dtype, void* stream);
+
+/*
  * 2-D single-head attention, float32, the reference's calling convention:
  *     o = softmax(scale * (q @ k_t)) @ v
  * q: [n, d]; k_t: [d, n] (K already transposed, as the reference's caller

@@ -61,6 +61,11 @@ CAUSAL_SHAPES = [(1, 2, 100, 64, 0.125), (2, 1, 257, 128, 1.0), (1, 1, 64, 40, 0
 BWD_SHAPES = [(1, 2, 100, 64, 0.125, False), (1, 2, 129, 128, 128 ** -0.5, True), (2, 1, 64, 64, 1.0, True)]
 
 
+# softmax along a dimension other than the last has no counterpart in the reference: pinned
+# against torch.softmax in float64.  (shape, dim)
+SOFTMAX_DIM_SHAPES = [((300, 130), 0), ((4, 37, 96), 1), ((2, 3, 50, 7), 2), ((3, 700, 5), 1), ((6, 33, 64), -1)]
+
+
 def load_reference(ref_root):
     sys.dont_write_bytecode = True
     sys.modules.setdefault("my_flash_attn_cuda", types.ModuleType("my_flash_attn_cuda"))
@@ -83,7 +88,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--only", default=None, help="regenerate one section only (softmax_dim), keeping the rest of the manifest")
     args = ap.parse_args()
+    if args.only == "softmax_dim":
+        with open(os.path.join(args.out, "MANIFEST.json")) as f:
+            manifest = json.load(f)
+        softmax_dim_section(args, manifest)
+        with open(os.path.join(args.out, "MANIFEST.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
     ref = load_reference(args.reference)
     os.makedirs(args.out, exist_ok=True)
     c_oracle.build()
@@ -200,9 +213,27 @@ def main():
         manifest["attention_bwd"][name] = rec
         print(name, rec)
 
+    softmax_dim_section(args, manifest)
+
     with open(os.path.join(args.out, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print("wrote", args.out)
+
+
+def softmax_dim_section(args, manifest):
+    manifest["softmax_dim"] = {}
+    for (shape, dim) in SOFTMAX_DIM_SHAPES:
+        torch.manual_seed(1)
+        x = torch.randn(*shape, dtype=torch.float32) * 3
+        o_pt = torch.softmax(x.double(), dim=dim).numpy()
+        o_np = ref_cpu.softmax_dim(x.numpy(), dim)
+        rec = {"oracle_np_vs_torch_f64": maxdiff(o_np, o_pt), "x_sha256": sha(x.numpy())}
+        assert rec["oracle_np_vs_torch_f64"] <= 1e-15, rec
+        name = "softmax_dim_" + "x".join(map(str, shape)) + f"_d{dim % len(shape)}"
+        np.savez_compressed(os.path.join(args.out, name + ".npz"), x=x.numpy(), dim=np.int64(dim),
+                            out_torch_f64=o_pt.astype(np.float32))
+        manifest["softmax_dim"][name] = rec
+        print(name, rec)
 
 
 if __name__ == "__main__":

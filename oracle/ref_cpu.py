@@ -47,6 +47,14 @@ def softmax_rows(x, dtype=np.float64):
     return e / e.sum(axis=1, keepdims=True)
 
 
+def softmax_dim(x, axis, dtype=np.float64):
+    """The same three steps along any one axis of an array of any rank: what
+    torch.softmax(x, dim) computes; axis = -1 of a 2-D array is softmax_rows."""
+    x = _as(x, dtype)
+    e = np.exp(x - x.max(axis=axis, keepdims=True))
+    return e / e.sum(axis=axis, keepdims=True)
+
+
 def attention_naive(q, k, v, scale=1.0, dtype=np.float64):
     """O = softmax(scale * Q K^T) V for 2-D Q, K, V of equal shape (N, d).
 

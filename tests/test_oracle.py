@@ -137,3 +137,21 @@ def test_c_oracle_query_row_sample(c_oracle):
     rows = np.array([0, 7, 49])
     part = c_oracle.attention(q[:, rows], k, v, scale=0.5)
     assert np.array_equal(part, full[:, rows])
+
+
+SOFTMAX_DIM = ["softmax_dim_300x130_d0", "softmax_dim_4x37x96_d1", "softmax_dim_2x3x50x7_d2",
+               "softmax_dim_3x700x5_d1", "softmax_dim_6x33x64_d2"]
+
+
+@pytest.mark.parametrize("name", SOFTMAX_DIM)
+def test_softmax_dim_oracle_vs_golden(name):
+    """softmax along any dimension: the numpy oracle against the stored float64 torch.softmax,
+    and against the row oracle on the tensor with that dimension moved last."""
+    g = load_golden(name)
+    x, dim = g["x"], int(g["dim"])
+    out = ref_cpu.softmax_dim(x, dim)
+    assert np.abs(out - g["out_torch_f64"]).max() <= 1e-7      # (the fixture is stored in float32)
+    assert np.allclose(out.sum(axis=dim), 1.0, atol=1e-12)
+    moved = np.moveaxis(x, dim, -1)
+    rows = ref_cpu.softmax_rows(moved.reshape(-1, moved.shape[-1])).reshape(moved.shape)
+    assert np.abs(np.moveaxis(rows, -1, dim) - out).max() <= 1e-15

@@ -5,12 +5,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "flash-attention_amd"))
 import torch
 import my_flash_attn_cuda as mfa
-B, H, N, d = 4, 32, 4096, 128
+args = dict(kv.split("=") for kv in sys.argv[1:])
+B, H, N, d = map(int, args.pop("shape", "4,32,4096,128").split(","))
 torch.manual_seed(1)
 q, k, v = (torch.randn(B, H, N, d, dtype=torch.bfloat16, device="cuda") for _ in range(3))
 nwg = B * H * (N // 256)
 dbg = torch.zeros(nwg * 24, dtype=torch.int64, device="cuda")
-for key, val in [kv.split("=") for kv in sys.argv[1:]]:
+for key, val in args.items():
     os.environ["MYFA_ATTN_" + key] = val
 os.environ["MYFA_ATTN_DBG"] = str(dbg.data_ptr())
 for _ in range(3):
@@ -25,5 +26,5 @@ for g in range(2):
 for g in range(2):
     print(f"wave {4*g} prologue cycles (median over WGs): " + "  ".join(f"{n}: {x[:, g, 7 + i].median().item():8.0f}" for i, n in enumerate(pro))
           + f"  total: {x[:, g, 5].median().item():8.0f}   epilogue: {x[:, g, 6].median().item():8.0f}")
-first = x[:256, 0, 5].median().item(); later = x[256:, 0, 5].median().item()
+first = x[:min(256, nwg // 2), 0, 5].median().item(); later = x[min(256, nwg // 2):, 0, 5].median().item()
 print(f"prologue of the first 256 workgroups: {first:.0f}; of the rest: {later:.0f}")
