@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Static check of the hand-written (inline asm) MFMAs in a HIP source.
+
+`Mma::acc_v / first_v` (csrc/attn_mfma_common.h) write their accumulator to VECTOR registers
+without the compiler knowing that the instruction is an MFMA, so the compiler inserts none of
+the wait states the hardware asks for between an MFMA and a vector instruction that touches its
+result (11 issue slots for the 8-pass 32x32x16 MFMA).  The kernels keep the distance by
+construction: the planned position of every consumer is at least two MFMAs behind the producer.
+The compiler may still move a vector instruction up within that window (nothing orders a pure
+instruction against an MFMA it does not depend on), so this script compiles the source to gfx950
+assembly and verifies the outcome on every kernel:
+
+    for every inline-asm MFMA with result v[a:b], no instruction other than an MFMA that
+    accumulates into the very same v[a:b] may name a register of v[a:b] until two more MFMAs
+    (each holds the issue port of the matrix core for its 8 passes) or 16 other instructions
+    (one issue slot each at least; the rule asks for 11) have been issued.
+
+    python tools/check_mfma_hazards.py flash-attention_amd/csrc/attn_bwd_mfma.hip [extra hipcc flags]
+
+Exit status 0 and a one-line summary if every kernel passes; 1 and the offending lines otherwise.
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MIN_MFMAS_BETWEEN = 2
+MIN_SLOTS_BETWEEN = 16
+REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def vregs(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def compile_to_asm(src, extra):
+    hipcc = "/opt/rocm/bin/hipcc"
+    out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(ROOT, "flash-attention_amd", "csrc"), "-S", "--cuda-device-only", "-o", out, src, *extra]
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    with open(out) as f:
+        text = f.read()
+    os.unlink(out)
+    return text
+
+
+def check(asm):
+    """Returns (number of inline-asm MFMAs seen, list of violations)."""
+    seen, bad = 0, []
+    kernel = None
+    in_asm = False
+    open_results = []       # [first, last, mfmas issued since, line text, issue slots since]
+    for n, line in enumerate(asm.split("\n"), 1):
+        s = line.strip()
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            kernel, open_results = m.group(1), []
+            continue
+        if s.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if s.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not s or s.startswith((";", ".", "//")) or s.endswith(":"):
+            continue
+        code = s.split(";")[0]
+        is_mfma = code.startswith("v_mfma")
+        ops = code.split(None, 1)[1] if " " in code else ""
+        dst = vregs(ops.split(",")[0]) if is_mfma else set()
+        touched = vregs(ops)
+        for r in open_results:
+            lo, hi = r[0], r[1]
+            if not any(lo <= v <= hi for v in touched):
+                continue
+            same_chain = is_mfma and dst == set(range(lo, hi + 1))
+            if not same_chain:
+                bad.append(f"{kernel}: line {n}: `{code}` touches v[{lo}:{hi}] {r[2]} MFMA(s) / {r[4]} slots after `{r[3]}`")
+        nop = re.match(r"s_nop\s+(\d+)", code)
+        for r in open_results:
+            r[4] += int(nop.group(1)) + 1 if nop else 1
+            if is_mfma:
+                r[2] += 1
+        open_results = [r for r in open_results if r[2] < MIN_MFMAS_BETWEEN and r[4] < MIN_SLOTS_BETWEEN
+                        and not (is_mfma and dst and dst == set(range(r[0], r[1] + 1)))]
+        if is_mfma and in_asm and dst:
+            seen += 1
+            open_results.append([min(dst), max(dst), 0, code, 0])
+    return seen, bad
+
+
+def main():
+    src = sys.argv[1]
+    seen, bad = check(compile_to_asm(src, sys.argv[2:]))
+    for b in bad:
+        print(b)
+    print(f"{os.path.basename(src)}: {seen} hand-written MFMAs, {len(bad)} result-latency violations")
+    return 1 if bad or not seen else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
