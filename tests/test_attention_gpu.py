@@ -89,6 +89,33 @@ def test_matmul_trio(mfa):
         mfa.my_matmul(torch.randn(3, 4, device="cuda"), torch.randn(5, 6, device="cuda"))
 
 
+@pytest.mark.parametrize("block", ["64", "128"])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (3, 7, 11), (128, 16, 128), (129, 17, 131), (260, 36, 132), (100, 200, 300),
+                                   (256, 4, 512), (130, 1000, 4), (512, 520, 388)])
+def test_matmul_both_kernels_small_shapes(mfa, monkeypatch, block, shape):
+    """Both block sizes forced on ragged and aligned shapes (vector and scalar staging)."""
+    monkeypatch.setenv("MYFA_MATMUL_BLOCK", block)
+    h, k, w = shape
+    torch.manual_seed(2)
+    a, b = torch.randn(h, k, device="cuda"), torch.randn(k, w, device="cuda")
+    ref = (a.double() @ b.double()).float()
+    assert torch.isclose(mfa.my_matmul(a, b), ref, atol=1e-4, rtol=1e-5).all()
+
+
+@pytest.mark.parametrize("shape", [(3000, 1000, 2900), (2999, 1001, 3001), (4096, 512, 4096), (8192, 64, 8192)])
+def test_matmul_large_blocks(mfa, shape):
+    """Shapes that the launcher gives to the 128 x 128 kernel (>= 512 blocks), aligned and not;
+    sampled rows against float64, everything against the vendor GEMM."""
+    h, k, w = shape
+    torch.manual_seed(3)
+    a, b = torch.randn(h, k, device="cuda"), torch.randn(k, w, device="cuda")
+    out = mfa.my_matmul(a, b)
+    rows = torch.tensor([0, 1, 63, 64, 127, 128, h // 2, h - 1], device="cuda")
+    ref = (a[rows].double() @ b.double()).float()
+    assert torch.isclose(out[rows], ref, atol=2e-4, rtol=1e-5).all()
+    assert float((out - torch.matmul(a, b)).abs().max()) <= 1e-3
+
+
 # ------------------------------------------------------------------ batched entry point
 
 def _rounded(x, dtype):

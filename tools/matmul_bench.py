@@ -9,7 +9,14 @@ def med(fn, it=20):
         a.record(); fn(); b.record()
     torch.cuda.synchronize()
     return sorted(a.elapsed_time(b) for a,b in ev)[it//2]
-for n in (1024, 4096, 8192):
+for n in (1024, 2048, 4096, 8192):
     a, b = torch.randn(n, n, device="cuda"), torch.randn(n, n, device="cuda")
-    t1 = med(lambda: mfa.my_matmul(a, b)); t2 = med(lambda: torch.matmul(a, b))
-    print(f"n={n}: my_matmul {t1:8.3f} ms {2*n**3/t1/1e9:7.1f} TF   vendor {t2:8.3f} ms {2*n**3/t2/1e9:7.1f} TF   maxdiff {float((mfa.my_matmul(a,b)-torch.matmul(a,b)).abs().max()):.2e}")
+    t2 = med(lambda: torch.matmul(a, b))
+    line = f"n={n}: vendor {t2:8.3f} ms {2*n**3/t2/1e9:7.1f} TF"
+    for blk in ("64", "128", ""):                       # "" = the library's own choice
+        os.environ.pop("MYFA_MATMUL_BLOCK", None)
+        if blk:
+            os.environ["MYFA_MATMUL_BLOCK"] = blk
+        t1 = med(lambda: mfa.my_matmul(a, b))
+        line += f"   block {blk or 'auto':4s} {t1:8.3f} ms {2*n**3/t1/1e9:7.1f} TF (maxdiff {float((mfa.my_matmul(a,b)-torch.matmul(a,b)).abs().max()):.1e})"
+    print(line, flush=True)
