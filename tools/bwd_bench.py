@@ -10,11 +10,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="4,32,4096,128")
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--causal", action="store_true")
+ap.add_argument("--fill", default="randn", choices=["randn", "ones"], help="ones: operands that toggle few bits (the power limit then binds less)")
 a = ap.parse_args()
 B, H, N, d = map(int, a.shape.split(","))
 dt = {"bf16": torch.bfloat16, "f16": torch.float16}[a.dtype]
 torch.manual_seed(1)
 q, k, v, do = (torch.randn(B, H, N, d, dtype=dt, device="cuda") for _ in range(4))
+if a.fill == "ones":
+    q, k, v, do = (torch.ones_like(x) for x in (q, k, v, do))
 scale = d ** -0.5
 out, lse = mfa.flash_attn_fwd(q, k, v, scale=scale, return_lse=True, causal=a.causal)
 
