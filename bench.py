@@ -18,6 +18,8 @@ collective on the timed path.  Rank 0 prints ONE JSON line:
                    against 8 TB/s HBM peak (rank 0, N=1 only)
   softmax_1024     my_softmax at 1024 x 1024 timed the way the reference's benchmark.py does, beside the
                    reference's published T4 numbers (the only timings it publishes)
+  softmax_dim      softmax along a non-last dimension (8 algorithmic B/element), and
+  matmul_f32       my_matmul at n^3 against the 157.3 TFLOP/s float32 MFMA peak beside the vendor GEMM
   cpu_config1      torch CPU timings of the CPU reference configuration (softmax 1024^2, naive attention
                    N=128 d=64), for reference beside the GPU numbers
   attention_f32    the float32 path (float64-MFMA logits + float32-MFMA P.V): the reference's
@@ -122,6 +124,41 @@ def bench_softmax_sweep(mfa, iters=20):
         res.append({"n": n, "us": round(med * 1e3, 2), "GB/s": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
         del xs, out
         torch.cuda.empty_cache()
+    return res
+
+
+def bench_softmax_dim(mfa):
+    """softmax along a non-last dimension: register-resident column blocks and streamed columns."""
+    res = []
+    for shape, dim in (((256, 64, 64, 64), 1), ((64, 128, 16384), 1), ((8192, 8192), 0)):
+        xs = [torch.randn(*shape, dtype=torch.float32, device="cuda") for _ in range(3)]
+        i = [0]
+
+        def run():
+            i[0] += 1
+            return mfa.softmax(xs[i[0] % 3], dim=dim)
+        ms = _median_ms(run, iters=20)
+        gbs = 2.0 * xs[0].numel() * 4 / (ms * 1e-3) / 1e9
+        res.append({"shape": list(shape), "dim": dim, "us": round(ms * 1e3, 2), "GB/s": round(gbs, 1),
+                    "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
+        del xs
+        torch.cuda.empty_cache()
+    return res
+
+
+def bench_matmul_f32(mfa):
+    """my_matmul (the library's float32 MFMA kernels) against the 157.3 TFLOP/s float32 MFMA peak,
+    beside the vendor GEMM on the same operands."""
+    res = []
+    for n in (1024, 4096, 8192):
+        a, b = torch.randn(n, n, device="cuda"), torch.randn(n, n, device="cuda")
+        ms = _median_ms(lambda: mfa.my_matmul(a, b), iters=10)
+        ms_v = _median_ms(lambda: torch.matmul(a, b), iters=10)
+        tf = 2.0 * n ** 3 / (ms * 1e-3) / 1e12
+        res.append({"n": n, "us": round(ms * 1e3, 1), "TFLOP/s": round(tf, 1), "frac_mfma_f32_peak": round(tf / 157.3, 4),
+                    "vendor_gemm_TFLOP/s": round(2.0 * n ** 3 / (ms_v * 1e-3) / 1e12, 1)})
+        del a, b
+    torch.cuda.empty_cache()
     return res
 
 
@@ -339,6 +376,8 @@ def main():
         result["attention_backward"] = bench_backward(mfa, B, H, N, d, dtype, scale)
         result["softmax_sweep"] = bench_softmax_sweep(mfa)
         result["softmax_1024"] = bench_softmax_1024(mfa)
+        result["softmax_dim"] = bench_softmax_dim(mfa)
+        result["matmul_f32"] = bench_matmul_f32(mfa)
         result["cpu_baseline"] = cpu_baseline(B, H, N, d, scale)
         result["cpu_config1"] = cpu_config1()
     elif rank == 0:
