@@ -18,6 +18,8 @@ which is what TORCH_CHECK raises through pybind), allocates the output with
 torch, and calls the HIP kernels through the C ABI in ``include/myfa.h`` on
 torch's *current* stream.  There is no CPU path: tensors must live on the GPU.
 """
+import contextlib
+
 import torch
 
 from . import _lib
@@ -45,8 +47,23 @@ def _check_float(x, name):
         raise RuntimeError(f"expected scalar type Float but found {x.dtype} for {name}")
 
 
+# Host cost of a call matters for the small shapes of the reference's tests (a 1024 x 1024 softmax
+# is 1.5 us of kernel): the raw handle of the current stream without building a Stream object, and
+# no device switch when the tensor's device is the current one already.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_NO_SWITCH = contextlib.nullcontext()
+
+
 def _stream():
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+def _on(t):
+    """Context that makes t's device current (the launch goes to that device's current stream)."""
+    idx = t.device.index
+    return _NO_SWITCH if idx == torch.cuda.current_device() else torch.cuda.device(idx)
 
 
 def my_softmax(inp, kernel_no=1):
@@ -65,7 +82,7 @@ def my_softmax(inp, kernel_no=1):
         raise RuntimeError(f"Unsupported kernel number: {kernel_no}")
     h, w = inp.shape
     out = torch.empty_like(inp)   # every element is written; no zero-fill pass
-    with torch.cuda.device(inp.device):
+    with _on(inp):
         _lib.check(_lib.lib.myfa_softmax_f32(inp.data_ptr(), out.data_ptr(), h, w, _stream()))
     return out
 
@@ -81,7 +98,7 @@ def softmax_rows(inp):
         raise RuntimeError(f"softmax_rows expects a 2-D tensor, got {inp.dim()}-D")
     h, w = inp.shape
     out = torch.empty_like(inp)
-    with torch.cuda.device(inp.device):
+    with _on(inp):
         _lib.check(_lib.lib.myfa_softmax(inp.data_ptr(), out.data_ptr(), h, w, _DTYPE_TAG[inp.dtype], _stream()))
     return out
 
@@ -105,7 +122,7 @@ def softmax(inp, dim=-1):
     for n in inp.shape[dim + 1:]:
         inner *= n
     out = torch.empty_like(inp)
-    with torch.cuda.device(inp.device):
+    with _on(inp):
         _lib.check(_lib.lib.myfa_softmax_nd(inp.data_ptr(), out.data_ptr(), outer, inp.shape[dim], inner,
                                             _DTYPE_TAG[inp.dtype], _stream()))
     return out
@@ -126,7 +143,7 @@ def my_attention(Q, K, V):
     if not (K.shape[0] == d and K.shape[1] == n and V.shape[0] == n and V.shape[1] == d):
         raise RuntimeError("Wrong sizes!")
     out = torch.empty_like(Q)
-    with torch.cuda.device(Q.device):
+    with _on(Q):
         _lib.check(_lib.lib.myfa_attn_fwd_f32(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(),
                                               n, d, 1.0, _stream()))
     return out
@@ -160,7 +177,7 @@ def flash_attn_fwd(q, k, v, scale=1.0, return_lse=False, causal=False):
     B, H, N, d = q.shape
     out = torch.empty_like(q)
     lse = torch.empty((B, H, N), dtype=torch.float32, device=q.device) if return_lse else None
-    with torch.cuda.device(q.device):
+    with _on(q):
         _lib.check(_lib.lib.myfa_attn_fwd_bhnd_ex(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
             lse.data_ptr() if return_lse else None,
@@ -186,7 +203,7 @@ def flash_attn_bwd(dout, q, k, v, out, lse, scale=1.0, causal=False):
         raise RuntimeError("lse must be the float32 (B, H, N) tensor returned by flash_attn_fwd")
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     delta = torch.empty((2, B, H, N), dtype=torch.float32, device=q.device)   # workspace: rowsum(dout * out), lse in base 2
-    with torch.cuda.device(q.device):
+    with _on(q):
         _lib.check(_lib.lib.myfa_attn_bwd_bhnd(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr(),
             dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(),
@@ -231,7 +248,7 @@ def _matmul_into(out, A, B):
     _check_float(A, "A"); _check_float(B, "B"); _check_float(out, "out")
     m, k = A.shape
     n = B.shape[1]
-    with torch.cuda.device(A.device):
+    with _on(A):
         _lib.check(_lib.lib.myfa_matmul_f32(A.data_ptr(), B.data_ptr(), out.data_ptr(), m, k, n, _stream()))
     return out
 
