@@ -28,6 +28,7 @@ collective on the timed path.  Rank 0 prints ONE JSON line:
                    104.8 TFLOP/s = 4 / (2/78.6 + 2/157.3), the two matrix rates in series
   attention_backward  the backward (delta, dQ, dK/dV kernels) of the same shape: ms, TFLOP/s over 2.5x
                    the forward's flops, and PyTorch's SDPA backward on the same tensors
+  attention_causal the same shape under the causal mask, forward and backward (half the products count)
   power_context    the same attention launch on all-ones operands, and the vendor bf16 GEMM
                    (torch.matmul -> hipBLASLt, 8192^3) on random and all-ones operands: the chip
                    lowers its clock under the power limit when operands are random, so these
@@ -254,6 +255,22 @@ def bench_backward(mfa, B, H, N, d, dtype, scale):
     return res
 
 
+def bench_causal(mfa, B, H, N, d, dtype, scale):
+    """The headline shape under the causal mask, forward and backward, counting the visible half of
+    the products (untimed context of the headline number)."""
+    torch.manual_seed(3)
+    q, k, v, do = (torch.randn(B, H, N, d, dtype=dtype, device="cuda") for _ in range(4))
+    out, lse = mfa.flash_attn_fwd(q, k, v, scale=scale, return_lse=True, causal=True)
+    ms_f = _median_ms(lambda: mfa.flash_attn_fwd(q, k, v, scale=scale, causal=True), iters=15)
+    ms_b = _median_ms(lambda: mfa.flash_attn_bwd(do, q, k, v, out, lse, scale=scale, causal=True), iters=10)
+    half = 0.5 * attn_flops(B, H, N, d)
+    res = {"forward_ms": round(ms_f, 3), "forward_TFLOP/s": round(half / ms_f / 1e9, 1),
+           "backward_ms": round(ms_b, 3), "backward_TFLOP/s_algorithmic": round(2.5 * half / ms_b / 1e9, 1)}
+    del q, k, v, do, out, lse
+    torch.cuda.empty_cache()
+    return res
+
+
 def cpu_baseline(B, H, N, d, scale, budget_s=12.0):
     """C oracle, float32 arithmetic, OpenMP: heads of the same workload until ~budget_s."""
     import numpy as np
@@ -374,6 +391,7 @@ def main():
         result["power_context"] = power_context(mfa, B, H, N, d, dtype, scale)
         result["attention_f32"] = bench_attention_f32(mfa)
         result["attention_backward"] = bench_backward(mfa, B, H, N, d, dtype, scale)
+        result["attention_causal"] = bench_causal(mfa, B, H, N, d, dtype, scale)
         result["softmax_sweep"] = bench_softmax_sweep(mfa)
         result["softmax_1024"] = bench_softmax_1024(mfa)
         result["softmax_dim"] = bench_softmax_dim(mfa)
