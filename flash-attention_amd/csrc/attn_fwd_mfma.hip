@@ -685,7 +685,8 @@ int launch(const void* q, const void* k, const void* v, void* o, float* lse,
                                static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
                                static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, tn.thr, tn.dbg);
         };
-        if (causal) go(attn_fwd_mfma_pp_kernel<T, D, false, true>);
+        if (causal && tn.dbg != nullptr) go(attn_fwd_mfma_pp_kernel<T, D, true, true>);
+        else if (causal) go(attn_fwd_mfma_pp_kernel<T, D, false, true>);
         else if (tn.dbg != nullptr) go(attn_fwd_mfma_pp_kernel<T, D, true>);
         else go(attn_fwd_mfma_pp_kernel<T, D, false>);
     }
