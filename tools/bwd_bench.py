@@ -10,6 +10,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="4,32,4096,128")
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--causal", action="store_true")
+ap.add_argument("--no-torch", action="store_true", help="skip the PyTorch SDPA backward (profiling runs)")
 ap.add_argument("--fill", default="randn", choices=["randn", "ones"], help="ones: operands that toggle few bits (the power limit then binds less)")
 a = ap.parse_args()
 B, H, N, d = map(int, a.shape.split(","))
@@ -39,6 +40,8 @@ t_f = med(lambda: mfa.flash_attn_fwd(q, k, v, scale=scale, return_lse=True, caus
 t_b = med(lambda: mfa.flash_attn_bwd(do, q, k, v, out, lse, scale=scale, causal=a.causal))
 print(f"forward  {t_f:8.3f} ms  {f / t_f / 1e9:8.1f} TFLOP/s")
 print(f"backward {t_b:8.3f} ms  {2.5 * f / t_b / 1e9:8.1f} TFLOP/s (algorithmic 2.5x forward)")
+if a.no_torch:
+    sys.exit(0)
 qf, kf, vf = (x.detach().clone().requires_grad_(True) for x in (q, k, v))
 o = torch.nn.functional.scaled_dot_product_attention(qf, kf, vf, is_causal=a.causal, scale=scale)
 t_t = med(lambda: torch.autograd.grad(o, (qf, kf, vf), do, retain_graph=True), it=7)
