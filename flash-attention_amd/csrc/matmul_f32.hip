@@ -30,8 +30,9 @@ template <bool VEC>
 __global__ void __launch_bounds__(256)
 sgemm_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                   int m, int k, int n) {
-    __shared__ float As[kBM * kAS];
-    __shared__ float Bs[kBK * kBS];
+    // two copies of each block: chunk i + 1 is published while chunk i is multiplied, one barrier per chunk
+    __shared__ float As[2][kBM * kAS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][kBK * kBS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
@@ -80,10 +81,10 @@ sgemm_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, floa
             }
         }
     };
-    auto publish = [&](int slot) __attribute__((always_inline)) {
+    auto publish = [&](int slot, int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) As[ar * kAS + ac + t] = ra[slot][t];
-        *reinterpret_cast<f32x4*>(&Bs[br * kBS + bc]) = rb[slot];
+        for (int t = 0; t < 4; ++t) As[buf][ar * kAS + ac + t] = ra[slot][t];
+        *reinterpret_cast<f32x4*>(&Bs[buf][br * kBS + bc]) = rb[slot];
     };
 
     f32x4 acc[2][2];
@@ -92,23 +93,28 @@ sgemm_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, floa
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    static_assert(kPF % 2 == 0, "the LDS copy of a chunk is chosen by the parity of its slot");
 #pragma unroll
-    for (int p = 0; p < kPF; ++p) fetch(p * kBK, p);      // (past the end: zero-filled, never published)
+    for (int p = 0; p < kPF; ++p) fetch(p * kBK, p);      // (past the end: zero-filled, published, never read)
+    publish(0, 0);
+    fetch(kPF * kBK, 0);
+    __syncthreads();
     for (int kb = 0; kb < k; kb += kPF * kBK) {
 #pragma unroll
         for (int p = 0; p < kPF; ++p) {
             const int k0 = kb + p * kBK;
             if (k0 < k) {                                  // uniform over the workgroup
-                publish(p);
-                __syncthreads();
-                fetch(k0 + kPF * kBK, p);
+                // chunk k0 is in copy p & 1; the next chunk goes into the other copy (last read one
+                // barrier ago) and its registers are refilled with the chunk kPF further on
+                publish((p + 1) % kPF, (p + 1) & 1);
+                fetch(k0 + (kPF + 1) * kBK, (p + 1) % kPF);
 #pragma unroll
                 for (int ks = 0; ks < kBK / 4; ++ks) {
                     float af[2], bf[2];
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) af[a] = As[(wm + 16 * a + j) * kAS + 4 * ks + g];
+                    for (int a = 0; a < 2; ++a) af[a] = As[p & 1][(wm + 16 * a + j) * kAS + 4 * ks + g];
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) bf[b] = Bs[(4 * ks + g) * kBS + wn + 16 * b + j];
+                    for (int b = 0; b < 2; ++b) bf[b] = Bs[p & 1][(4 * ks + g) * kBS + wn + 16 * b + j];
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
 #pragma unroll
