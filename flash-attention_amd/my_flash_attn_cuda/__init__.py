@@ -202,7 +202,7 @@ def flash_attn_bwd(dout, q, k, v, out, lse, scale=1.0, causal=False):
     if lse.dtype != torch.float32 or tuple(lse.shape) != (B, H, N):
         raise RuntimeError("lse must be the float32 (B, H, N) tensor returned by flash_attn_fwd")
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    delta = torch.empty((2, B, H, N), dtype=torch.float32, device=q.device)   # workspace: rowsum(dout * out), lse in base 2
+    delta = torch.empty((2, B, H, N), dtype=torch.float32, device=q.device)   # workspace: -rowsum(dout * out), lse in base 2
     with _on(q):
         _lib.check(_lib.lib.myfa_attn_bwd_bhnd(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr(),
