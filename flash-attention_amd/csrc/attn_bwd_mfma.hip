@@ -367,9 +367,11 @@ attn_bwd_dkv_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T*
     constexpr int TILE_B = kTile * D * 2;
     constexpr int KS = D / 16, DB = D / 32;
 
-    // Q0 Q1 dO0 dO1, then lse*log2e and delta of the tile's 64 queries, double-buffered
-    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_B + 4 * kTile * 4];
-    float* stat = reinterpret_cast<float*>(lds + 4 * TILE_B);     // [buf][lse2 | delta][64]
+    // Q0 Q1 Q2 dO0 dO1 dO2, then lse*log2e and -delta of the tile's 64 queries.  Three buffers: the
+    // requests for tile j + 2 are issued in the LAST steps of tile j (see the loop), into the buffer
+    // tile j - 1 was read from, while tile j + 1 is already complete.
+    __shared__ __attribute__((aligned(16))) char lds[6 * TILE_B + 6 * kTile * 4];
+    float* stat = reinterpret_cast<float*>(lds + 6 * TILE_B);     // [buf][lse2 | -delta][64]
 
     int lid;
     {
@@ -418,20 +420,25 @@ attn_bwd_dkv_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T*
     }
     // (the host pass of hipcc silently drops a kernel whose body names this builtin; the calls
     // only exist in the device pass)
-    auto fetch_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+    // piece i of a tile's fetch: even i this wave's KiB piece i/2 of Q, odd i that of dO
+    // (i < 2 LPT); piece 2 LPT the row statistics (wave 0)
+    auto fetch_piece = [&](int tile, int buf, auto i_) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (lds_void*)(lds + buf * TILE_B + 1024 * (wave * LPT + i)),
-                                                     16, st_goff[i], tile * TILE_B, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ors, (lds_void*)(lds + (2 + buf) * TILE_B + 1024 * (wave * LPT + i)),
-                                                     16, st_goff[i], tile * TILE_B, 0, 0);
-        }
-        if (wave == 0) {
+        constexpr int i = decltype(i_)::value;
+        if constexpr (i < 2 * LPT && i % 2 == 0) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (lds_void*)(lds + buf * TILE_B + 1024 * (wave * LPT + i / 2)),
+                                                     16, st_goff[i / 2], tile * TILE_B, 0, 0);
+        } else if constexpr (i < 2 * LPT) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ors, (lds_void*)(lds + (3 + buf) * TILE_B + 1024 * (wave * LPT + i / 2)),
+                                                     16, st_goff[i / 2], tile * TILE_B, 0, 0);
+        } else if (wave == 0) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(lrs, (lds_void*)(stat + buf * 2 * kTile), 4, lane * 4, tile * kTile * 4, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void*)(stat + buf * 2 * kTile + kTile), 4, lane * 4, tile * kTile * 4, 0, 0);
         }
 #endif
+    };
+    auto fetch_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+        static_for<2 * LPT + 1>([&](auto ic) __attribute__((always_inline)) { fetch_piece(tile, buf, ic); });
     };
 
     f32x16 dk[DB], dv[DB];
@@ -451,8 +458,10 @@ attn_bwd_dkv_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T*
     const int n_edge = k0 + BK > N ? n_tiles : has_tail + (CAUSAL ? min(2, n_tiles - has_tail) : 0);
     auto tile_of = [=](int j) __attribute__((always_inline)) { return (has_tail && j == 0) ? T_all - 1 : t0 + j - has_tail; };
     fetch_tile(tile_of(0), 0);
+    fetch_tile(tile_of(1), 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    int cur = 0, nxt = 1, fre = 2;                 // buffers of tile j, j + 1, j + 2
 
     // Per-lane bases of the fragment reads; everything else in an address is an immediate.
     //   row read of block qb, k-step ks: row 32qb + r, chunk 2ks + h
@@ -467,18 +476,17 @@ attn_bwd_dkv_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T*
     }
     using Plan = DkvPlanFor<KS>;
     static_assert(Plan::plan.ok && 4 * DB == 2 * KS, "every vector operation placed before its deadline");
-    constexpr int NSTEP = 8 * KS, FW = 8;
+    // FW: fragments requested ahead of the MFMA stream.  The tile's last FW steps request none, and
+    // that is where the next-but-one tile's loads are issued, one piece every PSTEP steps.
+    constexpr int NSTEP = 8 * KS, FW = D == 128 ? 16 : 8, PSTEP = FW / (2 * LPT);
+    static_assert(PSTEP >= 1 && PSTEP * 2 * LPT == FW, "the tile's loads fill its last FW steps");
 
     auto run_tiles = [&](int j0, int j1, auto edge_) __attribute__((always_inline)) {
     for (int j = j0; j < j1; ++j) {
-        const int buf = j & 1;
         const int qt0 = tile_of(j) * kTile;
-        // the next tile into the other buffer (last read before the previous barrier); unconditional
-        // (behind the last tile: a tile nobody reads).  It has the whole tile's compute to land.
-        fetch_tile(tile_of(j + 1), buf ^ 1);
-        const char* Qb = lds + buf * TILE_B;
-        const char* dOb = lds + (2 + buf) * TILE_B;
-        const float* lse2b = stat + buf * 2 * kTile;
+        const char* Qb = lds + cur * TILE_B;
+        const char* dOb = lds + (3 + cur) * TILE_B;
+        const float* lse2b = stat + cur * 2 * kTile;
         const float* ndelb = lse2b + kTile;
 
         // S = Q K^T and dP = dO V^T put the key on the lane; accumulator register i of block qb is
@@ -569,13 +577,31 @@ attn_bwd_dkv_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T*
             const s16x8 a = win[g % FW];
             mma(gc, a);
             if constexpr (g + FW < NSTEP) win[g % FW] = frag(IC<g + FW>{});
+            // Tile j + 2 into the buffer tile j - 1 was read from (everybody left it at the last
+            // barrier; unconditional, past the end a tile nobody reads), spread over the tile's last
+            // FW steps.  Two facts set this placement.  All four waves run in lock step, and the
+            // 34 load instructions of a tile issued back to back at the top of the tile took the
+            // one texture path of the CU some 900 cycles, a quarter of the tile, with every wave
+            // held at its loads and every matrix core idle.  And hipcc makes each transposing LDS
+            // read wait for ALL LDS-DMA loads in flight, so loads may only be issued where no such
+            // read follows soon: behind the tile's last fragment request.  The wait in front
+            // confirms this wave's pieces of tile j + 1, issued a tile ago.
+            if constexpr (g == NSTEP - FW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (g >= NSTEP - FW && (g - (NSTEP - FW)) % PSTEP == 0)
+                fetch_piece(tile_of(j + 2), fre, IC<(g - (NSTEP - FW)) / PSTEP>{});
+            if constexpr (g == NSTEP - 1) fetch_piece(tile_of(j + 2), fre, IC<2 * LPT>{});
             constexpr int o0 = Plan::plan.start[g], o1 = Plan::plan.start[g + 1];
             static_for<o1 - o0>([&](auto oc) __attribute__((always_inline)) { vop(edge_, IC<o0 + decltype(oc)::value>{}); });
             __builtin_amdgcn_sched_barrier(0);
         });
 
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next tile are in
-        __syncthreads();
+        // tile j + 1 complete (all waves' pieces), tile j released.  The bare barrier: __syncthreads()
+        // would first wait for the loads of tile j + 2 issued a moment ago.
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int was = cur;
+        cur = nxt; nxt = fre; fre = was;
     }
     };
     run_tiles(0, n_edge, IC<1>{});
