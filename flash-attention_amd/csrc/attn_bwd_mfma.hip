@@ -478,7 +478,7 @@ attn_bwd_dkv_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T*
     static_assert(Plan::plan.ok && 4 * DB == 2 * KS, "every vector operation placed before its deadline");
     // FW: fragments requested ahead of the MFMA stream.  The tile's last FW steps request none, and
     // that is where the next-but-one tile's loads are issued, one piece every PSTEP steps.
-    constexpr int NSTEP = 8 * KS, FW = D == 128 ? 16 : 8, PSTEP = FW / (2 * LPT);
+    constexpr int NSTEP = 8 * KS, FW = 8, PSTEP = FW / (2 * LPT);
     static_assert(PSTEP >= 1 && PSTEP * 2 * LPT == FW, "the tile's loads fill its last FW steps");
 
     auto run_tiles = [&](int j0, int j1, auto edge_) __attribute__((always_inline)) {
