@@ -76,7 +76,9 @@ attn_bwd_dq_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* 
     constexpr int TILE_B = kTile * D * 2;
     constexpr int KS = D / 16, DB = D / 32;
 
-    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_B];   // K0 K1 V0 V1
+    // K0 K1 K2 V0 V1 V2: three buffers, the loads of tile t + 2 go out in the last steps of tile t
+    // (see the dK/dV kernel for why there and not at the top of the tile)
+    __shared__ __attribute__((aligned(16))) char lds[6 * TILE_B];
 
     int lid;
     {
@@ -128,23 +130,29 @@ attn_bwd_dq_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* 
     }
     // (the host pass of hipcc silently drops a kernel whose body names this builtin; the calls
     // only exist in the device pass)
-    auto fetch_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+    // piece p of a tile's fetch: even p this wave's KiB piece p/2 of K, odd p that of V (p < 2 LPT)
+    auto fetch_piece = [&](int tile, int buf, int p) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_void*)(lds + buf * TILE_B + 1024 * (wave * LPT + i)),
-                                                     16, st_goff[i], tile * TILE_B, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_void*)(lds + (2 + buf) * TILE_B + 1024 * (wave * LPT + i)),
-                                                     16, st_goff[i], tile * TILE_B, 0, 0);
-        }
+        if ((p & 1) == 0)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_void*)(lds + buf * TILE_B + 1024 * (wave * LPT + p / 2)),
+                                                     16, st_goff[p / 2], tile * TILE_B, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_void*)(lds + (3 + buf) * TILE_B + 1024 * (wave * LPT + p / 2)),
+                                                     16, st_goff[p / 2], tile * TILE_B, 0, 0);
 #endif
+    };
+    auto fetch_tile = [&](int tile, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 2 * LPT; ++p) fetch_piece(tile, buf, p);
     };
 
     const int T_all = (N + kTile - 1) / kTile;
     const int ntiles = CAUSAL ? min(T_all, (q0 + BQ) / kTile) : T_all;
     fetch_tile(0, 0);
+    fetch_tile(1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    int cur = 0, nxt = 1, fre = 2;                 // buffers of tile t, t + 1, t + 2
 
     // Per-lane bases of the fragment reads; everything else in an address is an immediate.
     const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
@@ -174,13 +182,9 @@ attn_bwd_dq_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* 
     auto nothing = [](int) __attribute__((always_inline)) {};
 
     for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
         const int kv0 = t * kTile;
-        // the next tile into the other buffer (last read before the previous barrier); unconditional,
-        // a tile past the end reads zeros
-        fetch_tile(t + 1, buf ^ 1);
-        const char* Kb = lds + buf * TILE_B;
-        const char* Vb = lds + (2 + buf) * TILE_B;
+        const char* Kb = lds + cur * TILE_B;
+        const char* Vb = lds + (3 + cur) * TILE_B;
 
         // The tile's 64 keys are two blocks of 32, staggered so that the vector part of one block
         // runs in the shadow of the other block's MFMAs:
@@ -258,10 +262,25 @@ attn_bwd_dq_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* 
         finish(1);
         stream(IC<2 * DB>{},                                                                       // D
                [&](int i) __attribute__((always_inline)) -> s16x8 { return tr_frag(1, i); },
-               [&](int i, s16x8 a) __attribute__((always_inline)) { tr_mma(1, i, a); }, nothing);
+               [&](int i, s16x8 a) __attribute__((always_inline)) { tr_mma(1, i, a); },
+               [&](int i) __attribute__((always_inline)) {
+                   // Tile t + 2 into the buffer tile t - 1 was read from (everybody left it at the last
+                   // barrier; unconditional, a tile past the end reads zeros): one piece per step over
+                   // the phase's last steps, behind the tile's last fragment request.  The wait in
+                   // front confirms this wave's pieces of tile t + 1, issued a tile ago.
+                   constexpr int P0 = 2 * DB - 2 * LPT;
+                   static_assert(P0 >= 0 && (2 * DB <= FW || P0 >= 2 * DB - FW), "the loads follow the last fragment request");
+                   if (i == P0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                   if (i >= P0) fetch_piece(t + 2, fre, i - P0);
+               });
 
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next tile are in
-        __syncthreads();
+        // tile t + 1 complete (all waves' pieces), tile t released; the bare barrier, not
+        // __syncthreads(), which would first wait for the loads issued a moment ago
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int was = cur;
+        cur = nxt; nxt = fre; fre = was;
     }
 
     if (qrow < N) {
