@@ -149,7 +149,7 @@ attn_bwd_dq_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* 
     const int T_all = (N + kTile - 1) / kTile;
     const int ntiles = CAUSAL ? min(T_all, (q0 + BQ) / kTile) : T_all;
     fetch_tile(0, 0);
-    fetch_tile(1, 1);
+    fetch_tile(1 < ntiles ? 1 : T_all, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int cur = 0, nxt = 1, fre = 2;                 // buffers of tile t, t + 1, t + 2
@@ -271,7 +271,9 @@ attn_bwd_dq_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* 
                    constexpr int P0 = 2 * DB - 2 * LPT;
                    static_assert(P0 >= 0 && (2 * DB <= FW || P0 >= 2 * DB - FW), "the loads follow the last fragment request");
                    if (i == P0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                   if (i >= P0) fetch_piece(t + 2, fre, i - P0);
+                   // (under the causal mask the tiles behind the block's last one exist but are never
+                   // read: asked for as the tile past the end, the bounds check answers with zeros)
+                   if (i >= P0) fetch_piece(t + 2 < ntiles ? t + 2 : T_all, fre, i - P0);
                });
 
         // tile t + 1 complete (all waves' pieces), tile t released; the bare barrier, not

@@ -349,10 +349,17 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
     }
     // (The host pass of hipcc silently drops a kernel whose body names this builtin, and the
     // launch stub with it; the body only exists in the device pass.)
+    // Under the causal mask the tiles behind the workgroup's last one exist but are never read:
+    // they are asked for as the tile past the end, which the bounds check answers with zeros
+    // without touching memory (the unconditional fetches at the end of the loop would otherwise
+    // load two or three real tiles per workgroup, and the epilogue would wait for them).
+    [[maybe_unused]] const int t_past = (N + kBKV - 1) / kBKV;
+    [[maybe_unused]] const int t_stop = CAUSAL ? min(t_past, (q0 + kBQ) / kBKV) : t_past;
     auto fetch_piece = [&](const __amdgpu_buffer_rsrc_t& rs, int tile, int lds_byte, int i) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
+        const int te = CAUSAL ? (tile < t_stop ? tile : t_past) : tile;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + lds_byte + 1024 * (wave_u * LPT + i)),
-                                                 16, st_goff[i], tile * TILE_B, 0, 0);
+                                                 16, st_goff[i], te * TILE_B, 0, 0);
 #endif
     };
     auto fetch_k = [&](int tile, int slot) __attribute__((always_inline)) {
