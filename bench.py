@@ -261,8 +261,8 @@ def bench_causal(mfa, B, H, N, d, dtype, scale):
     torch.manual_seed(3)
     q, k, v, do = (torch.randn(B, H, N, d, dtype=dtype, device="cuda") for _ in range(4))
     out, lse = mfa.flash_attn_fwd(q, k, v, scale=scale, return_lse=True, causal=True)
-    ms_f = _median_ms(lambda: mfa.flash_attn_fwd(q, k, v, scale=scale, causal=True), iters=15)
-    ms_b = _median_ms(lambda: mfa.flash_attn_bwd(do, q, k, v, out, lse, scale=scale, causal=True), iters=10)
+    ms_f = _median_ms(lambda: mfa.flash_attn_fwd(q, k, v, scale=scale, causal=True), iters=30, warm=PRIMING)
+    ms_b = _median_ms(lambda: mfa.flash_attn_bwd(do, q, k, v, out, lse, scale=scale, causal=True), iters=15, warm=5)
     half = 0.5 * attn_flops(B, H, N, d)
     res = {"forward_ms": round(ms_f, 3), "forward_TFLOP/s": round(half / ms_f / 1e9, 1),
            "backward_ms": round(ms_b, 3), "backward_TFLOP/s_algorithmic": round(2.5 * half / ms_b / 1e9, 1)}
