@@ -27,6 +27,8 @@
 // atomics on dQ).
 #include "attn_mfma_common.h"
 
+#include <mutex>
+
 namespace myfa {
 namespace {
 
@@ -675,7 +677,61 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     return check_launch("attn_bwd_mfma");
 }
 
+// ---- the allocation-free entry point's workspace -------------------------------------------
+// A file-scope device array takes the place of the caller's `delta_ws`.  Every GPU the library
+// runs on holds its own copy (8 MiB) from the moment the code object is loaded there until the
+// process ends.  The array's name is only a handle on the host: its address on a device comes
+// from hipGetSymbolAddress, asked once per device with that device current, and that pointer is
+// what the kernels receive.
+constexpr int64_t kScratchFloats = 2 * 1048576;   // 2 * B*H*N floats, B*H*N <= 2^20
+static __device__ __align__(256) float scratch[kScratchFloats];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+float* g_scratch_ptr[kMaxDevices] = {};
+
+// Device address of `scratch` on the current device (nullptr + error message on failure).
+float* scratch_on_current_device() {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        fail(MYFA_E_DEVICE, "attention backward (static workspace): no usable current device (%s)", hipGetErrorString(e));
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || p == nullptr) {
+            fail(MYFA_E_DEVICE, "attention backward (static workspace): hipGetSymbolAddress on device %d: %s", dev, hipGetErrorString(e));
+            return nullptr;
+        }
+        g_scratch_ptr[dev] = static_cast<float*>(p);
+    }
+    return g_scratch_ptr[dev];
+}
+
 }  // namespace
+
+// The backward with the [2, heads, N] float workspace in the library's own device array instead
+// of a caller buffer.  Nothing in the array has to start at zero: the delta kernel writes all
+// 2 * heads * N words before the other two kernels read them.  Calls that overlap on one GPU
+// (different streams) share the array and race.
+int attn_bwd_mfma(const void* q, const void* k, const void* v, const void* o, const float* lse, const void* dout,
+                  void* dq, void* dk, void* dv, float* delta, int64_t heads, int64_t N, int64_t d,
+                  float scale, int dtype, bool causal, hipStream_t s);
+int attn_bwd_mfma_static_ws(const void* q, const void* k, const void* v, const void* o, const float* lse, const void* dout,
+                            void* dq, void* dk, void* dv, int64_t heads, int64_t N, int64_t d,
+                            float scale, int dtype, bool causal, hipStream_t s) {
+    if (heads > kScratchFloats / 2 || N > kScratchFloats / 2 || 2 * heads * N > kScratchFloats)
+        return fail(MYFA_E_UNSUPPORTED,
+                    "attention backward (static workspace): B*H*N = %lld exceeds the built-in workspace of %lld rows; "
+                    "use myfa_attn_bwd_bhnd with a caller workspace",
+                    (long long)(heads * N), (long long)(kScratchFloats / 2));
+    float* ws = scratch_on_current_device();
+    if (ws == nullptr) return MYFA_E_DEVICE;
+    return attn_bwd_mfma(q, k, v, o, lse, dout, dq, dk, dv, ws, heads, N, d, scale, dtype, causal, s);
+}
 
 // dtype: MYFA_F16 or MYFA_BF16; d: 64 or 128; heads = B*H.  `delta` is a caller-provided
 // float32 workspace of 2 * heads * N elements (the library allocates nothing).

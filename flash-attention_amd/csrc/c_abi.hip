@@ -41,6 +41,9 @@ int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* l
 int attn_bwd_mfma(const void* q, const void* k, const void* v, const void* o, const float* lse, const void* dout,
                   void* dq, void* dk, void* dv, float* delta, int64_t heads, int64_t N, int64_t d,
                   float scale, int dtype, bool causal, hipStream_t s);
+int attn_bwd_mfma_static_ws(const void* q, const void* k, const void* v, const void* o, const float* lse, const void* dout,
+                            void* dq, void* dk, void* dv, int64_t heads, int64_t N, int64_t d,
+                            float scale, int dtype, bool causal, hipStream_t s);
 
 }  // namespace myfa
 
@@ -138,6 +141,28 @@ int myfa_attn_bwd_bhnd(const void* q, const void* k, const void* v, const void* 
         return fail(MYFA_E_INVALID, "attention backward: tensors must be 16-byte aligned");
     return attn_bwd_mfma(q, k, v, o, lse, dout, dq, dk, dv, delta_ws, B * H, N, d, scale, dtype,
                          (flags & MYFA_ATTN_CAUSAL) != 0, static_cast<hipStream_t>(stream));
+}
+
+int myfa_attn_bwd_bhnd_static_ws(const void* q, const void* k, const void* v, const void* o, const float* lse,
+                                 const void* dout, void* dq, void* dk, void* dv,
+                                 int64_t B, int64_t H, int64_t N, int64_t d, float scale, int dtype, int flags, void* stream) {
+    if (B < 0 || H < 0 || N < 0 || d < 0)
+        return fail(MYFA_E_INVALID, "attention backward: negative size B=%lld H=%lld N=%lld d=%lld",
+                    (long long)B, (long long)H, (long long)N, (long long)d);
+    if ((flags & ~MYFA_ATTN_CAUSAL) != 0) return fail(MYFA_E_INVALID, "attention backward: unknown flag bits 0x%x", flags);
+    if (B == 0 || H == 0 || N == 0 || d == 0) return MYFA_OK;
+    if (!q || !k || !v || !o || !lse || !dout || !dq || !dk || !dv)
+        return fail(MYFA_E_INVALID, "attention backward: null pointer");
+    if (dtype != MYFA_F16 && dtype != MYFA_BF16)
+        return fail(MYFA_E_UNSUPPORTED, "attention backward: float16 or bfloat16 only (dtype tag %d)", dtype);
+    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
+         reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dq) |
+         reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv)) % 16 != 0)
+        return fail(MYFA_E_INVALID, "attention backward: tensors must be 16-byte aligned");
+    if (B > MYFA_BWD_STATIC_WS_ROWS || H > MYFA_BWD_STATIC_WS_ROWS || B * H > MYFA_BWD_STATIC_WS_ROWS)
+        return fail(MYFA_E_UNSUPPORTED, "attention backward (static workspace): B*H*N exceeds %d rows", MYFA_BWD_STATIC_WS_ROWS);
+    return attn_bwd_mfma_static_ws(q, k, v, o, lse, dout, dq, dk, dv, B * H, N, d, scale, dtype,
+                                   (flags & MYFA_ATTN_CAUSAL) != 0, static_cast<hipStream_t>(stream));
 }
 
 int myfa_matmul_f32(const float* a, const float* b, float* c, int64_t m, int64_t k, int64_t n, void* stream) {

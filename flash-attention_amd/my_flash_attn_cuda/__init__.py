@@ -26,7 +26,7 @@ from . import _lib
 from ._lib import MYFA_BF16, MYFA_F16, MYFA_F32, device_info  # noqa: F401
 
 __all__ = ["my_softmax", "my_attention", "my_matmul", "my_matmul_cublas", "my_matmul_out",
-           "flash_attn_fwd", "flash_attn_bwd", "flash_attn_func", "softmax_rows", "softmax", "device_info"]
+           "flash_attn_fwd", "flash_attn_bwd", "flash_attn_bwd_into", "flash_attn_func", "softmax_rows", "softmax", "device_info"]
 
 _DTYPE_TAG = {torch.float32: MYFA_F32, torch.float16: MYFA_F16, torch.bfloat16: MYFA_BF16}
 
@@ -39,6 +39,11 @@ def _check_input(x, name):
         raise RuntimeError(f"{name} must be a CUDA tensor")
     if not x.is_contiguous():
         raise RuntimeError(f"{name} must be contiguous")
+
+
+def _same_device(x, ref, name):
+    if x.device != ref.device:
+        raise RuntimeError(f"{name} is on {x.device}, expected {ref.device}: all operands must be on one device")
 
 
 def _check_float(x, name):
@@ -207,6 +212,33 @@ def flash_attn_bwd(dout, q, k, v, out, lse, scale=1.0, causal=False):
         _lib.check(_lib.lib.myfa_attn_bwd_bhnd(
             q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr(),
             dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr(),
+            B, H, N, d, float(scale), _DTYPE_TAG[q.dtype], ATTN_CAUSAL if causal else 0, _stream()))
+    return dq, dk, dv
+
+
+BWD_STATIC_WS_ROWS = 1048576   # MYFA_BWD_STATIC_WS_ROWS
+
+
+def flash_attn_bwd_into(dout, q, k, v, out, lse, dq, dk, dv, scale=1.0, causal=False):
+    """flash_attn_bwd for callers that may not allocate: the gradients go into the caller's
+    dq, dk, dv and the workspace is the library's own device array (B*H*N <= BWD_STATIC_WS_ROWS;
+    calls that overlap on one GPU race on it).  Results equal flash_attn_bwd's bit for bit."""
+    for t, name in ((dout, "dout"), (q, "q"), (k, "k"), (v, "v"), (out, "out"), (lse, "lse"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        _check_input(t, name)
+        _same_device(t, q, name)
+    if q.dim() != 4 or not (q.shape == k.shape == v.shape == out.shape == dout.shape == dq.shape == dk.shape == dv.shape):
+        raise RuntimeError("Wrong sizes!")
+    if not (q.dtype == k.dtype == v.dtype == out.dtype == dout.dtype == dq.dtype == dk.dtype == dv.dtype):
+        raise RuntimeError("Scalar type mismatch!")
+    if q.dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError(f"flash_attn_bwd supports float16 and bfloat16, got {q.dtype}")
+    B, H, N, d = q.shape
+    if lse.dtype != torch.float32 or tuple(lse.shape) != (B, H, N):
+        raise RuntimeError("lse must be the float32 (B, H, N) tensor returned by flash_attn_fwd")
+    with _on(q):
+        _lib.check(_lib.lib.myfa_attn_bwd_bhnd_static_ws(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr(),
+            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
             B, H, N, d, float(scale), _DTYPE_TAG[q.dtype], ATTN_CAUSAL if causal else 0, _stream()))
     return dq, dk, dv
 

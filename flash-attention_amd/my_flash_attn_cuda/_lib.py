@@ -25,6 +25,7 @@ EXPORTS = (
     "myfa_attn_fwd_bhnd",
     "myfa_attn_fwd_bhnd_ex",
     "myfa_attn_bwd_bhnd",
+    "myfa_attn_bwd_bhnd_static_ws",
     "myfa_matmul_f32",
 )
 
@@ -57,6 +58,8 @@ def _load():
     lib.myfa_attn_fwd_bhnd_ex.restype = ci
     lib.myfa_attn_bwd_bhnd.argtypes = [vp] * 10 + [i64, i64, i64, i64, f32, ci, ci, vp]
     lib.myfa_attn_bwd_bhnd.restype = ci
+    lib.myfa_attn_bwd_bhnd_static_ws.argtypes = [vp] * 9 + [i64, i64, i64, i64, f32, ci, ci, vp]
+    lib.myfa_attn_bwd_bhnd_static_ws.restype = ci
     lib.myfa_matmul_f32.argtypes = [vp, vp, vp, i64, i64, i64, vp]
     lib.myfa_matmul_f32.restype = ci
     got = lib.myfa_abi_version()

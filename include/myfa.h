@@ -158,6 +158,24 @@ int myfa_attn_bwd_bhnd(const void* q, const void* k, const void* v, const void* 
                        float scale, int dtype, int flags, void* stream);
 
 /*
+ * myfa_attn_bwd_bhnd without the workspace argument, for callers that cannot allocate device
+ * memory (code under HIP graph capture, tight serving loops, harnesses that forbid it): the
+ * 2*B*H*N float workspace lives in a device array inside the library (8 MiB, held by every GPU
+ * the library runs on until the process ends), so the call allocates nothing and takes only
+ * inputs and outputs.  No counterpart in the reference.
+ * Limit: B*H*N <= MYFA_BWD_STATIC_WS_ROWS, otherwise MYFA_E_UNSUPPORTED (use myfa_attn_bwd_bhnd).
+ * All calls on one GPU share that array: calls that overlap on one GPU (different streams)
+ * race; calls on one stream, or ordered by events, are fine.  Results are those of
+ * myfa_attn_bwd_bhnd bit for bit.  The array's device address is looked up on the first call
+ * on each device (make that call outside any graph capture).
+ */
+#define MYFA_BWD_STATIC_WS_ROWS 1048576
+int myfa_attn_bwd_bhnd_static_ws(const void* q, const void* k, const void* v, const void* o, const float* lse,
+                                 const void* dout, void* dq, void* dk, void* dv,
+                                 int64_t B, int64_t H, int64_t N, int64_t d,
+                                 float scale, int dtype, int flags, void* stream);
+
+/*
  * c[m, n] = a[m, k] . b[k, n], float32, dense row-major.  Replaces the reference's
  * own tiled kernel behind my_matmul / my_matmul_out (launch_matmul_kernel,
  * csrc/my_flash_attn/matmul.cu:22-62, called from csrc/api.cpp:13-66).  Every
