@@ -21,14 +21,19 @@ INCLUDE = os.path.join(ROOT, "include")
 OBJ = os.path.join(CSRC, ".obj")
 PKG = os.path.join(HERE, "my_flash_attn_cuda")
 LIB = os.path.join(PKG, "libmyfa_gfx950.so")
+# The same sources with -DMYFA_TUNING: launch knobs settable at run time through two extra
+# exported functions (csrc/tuning.h).  For tools/ and the tests that compare kernel variants;
+# the package never loads it unless MYFA_LIBRARY names it.
+LIB_TUNING = os.path.join(PKG, "libmyfa_gfx950_tuning.so")
 
-SOURCES = ["c_abi.hip", "softmax_rows.hip", "softmax_strided.hip", "attn_fwd_f32.hip", "attn_fwd_mfma.hip", "attn_bwd_mfma.hip", "matmul_f32.hip"]
+SOURCES = ["c_abi.hip", "softmax_rows.hip", "softmax_strided.hip", "attn_fwd_f32.hip", "attn_fwd_mfma.hip",
+           "attn_fwd_mfma16.hip", "attn_bwd_mfma.hip", "matmul_f32.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + INCLUDE, "-I" + CSRC,
          "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
 # The backward kernels place every vector instruction by hand between MFMAs; the SLP vectoriser
 # regroups them into packed float32 pairs with register shuffles around them.
-PER_SOURCE_FLAGS = {"attn_bwd_mfma.hip": ["-fno-slp-vectorize"]}
+PER_SOURCE_FLAGS = {"attn_bwd_mfma.hip": ["-fno-slp-vectorize"], "attn_fwd_mfma16.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -44,8 +49,8 @@ def _newest_header():
     return max(os.path.getmtime(h) for h in hs)
 
 
-def _compile(src, extra):
-    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+def _compile(src, extra, objdir=OBJ):
+    obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
     stamp = max(os.path.getmtime(path), _newest_header(), os.path.getmtime(__file__))
     if os.path.exists(obj) and os.path.getmtime(obj) >= stamp:
@@ -54,23 +59,31 @@ def _compile(src, extra):
     return obj, True
 
 
-def build_library(force=False, verbose=True, extra_flags=()):
-    """Compile every HIP source for gfx950 and link the shared library."""
-    os.makedirs(OBJ, exist_ok=True)
+def _build_one(lib, objdir, flags, force, verbose):
+    os.makedirs(objdir, exist_ok=True)
     if force:
-        for f in os.listdir(OBJ):
-            os.remove(os.path.join(OBJ, f))
+        for f in os.listdir(objdir):
+            os.remove(os.path.join(objdir, f))
     with ThreadPoolExecutor(max_workers=4) as ex:
-        results = list(ex.map(lambda s: _compile(s, list(extra_flags)), SOURCES))
+        results = list(ex.map(lambda s: _compile(s, list(flags), objdir), SOURCES))
     objs = [o for o, _ in results]
     rebuilt = any(c for _, c in results)
-    if rebuilt or not os.path.exists(LIB):
-        subprocess.check_call([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs])
+    if rebuilt or not os.path.exists(lib):
+        subprocess.check_call([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib, *objs])
         if verbose:
-            print(f"[myfa] linked {LIB}")
+            print(f"[myfa] linked {lib}")
     elif verbose:
-        print(f"[myfa] up to date: {LIB}")
-    return LIB
+        print(f"[myfa] up to date: {lib}")
+    return lib
+
+
+def build_library(force=False, verbose=True, extra_flags=(), tuning=True):
+    """Compile every HIP source for gfx950 and link the shared library (and, unless tuning=False,
+    its tuning flavour)."""
+    lib = _build_one(LIB, OBJ, list(extra_flags), force, verbose)
+    if tuning:
+        _build_one(LIB_TUNING, OBJ + "_tuning", [*extra_flags, "-DMYFA_TUNING"], force, verbose)
+    return lib
 
 
 if __name__ == "__main__":

@@ -657,21 +657,21 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     const T* dO = static_cast<const T*>(dout);
     const int64_t rows = heads * N;
     constexpr int RPB = 256 / (D / 8);
-    hipLaunchKernelGGL((attn_bwd_delta_kernel<T, D>), dim3((unsigned)cdiv(rows, RPB)), dim3(256), 0, s, O, dO, lse, delta, (long long)rows);
+    launch_kernel((attn_bwd_delta_kernel<T, D>), dim3((unsigned)cdiv(rows, RPB)), dim3(256), 0, s, O, dO, lse, delta, (long long)rows);
     const float* lse2 = delta + rows;
 
     const int64_t nqblk = cdiv(N, 256), nkblk = cdiv(N, 128);
     const int64_t nq = heads * nqblk, nk = heads * nkblk;
     if (nq > 0x7fffffffLL || nk > 0x7fffffffLL) return fail(MYFA_E_UNSUPPORTED, "attention backward: too many workgroups");
     if (causal) {
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, true>), dim3((unsigned)nk), dim3(256), 0, s, Q, K, V, dO, lse2, delta,
+        launch_kernel((attn_bwd_dkv_kernel<T, D, true>), dim3((unsigned)nk), dim3(256), 0, s, Q, K, V, dO, lse2, delta,
                            static_cast<T*>(dk), static_cast<T*>(dv), (int)N, (int)nkblk, (int)nk, scale);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, true>), dim3((unsigned)nq), dim3(512), 0, s, Q, K, V, dO, lse, delta,
+        launch_kernel((attn_bwd_dq_kernel<T, D, true>), dim3((unsigned)nq), dim3(512), 0, s, Q, K, V, dO, lse, delta,
                            static_cast<T*>(dq), (int)N, (int)nqblk, (int)nq, scale);
     } else {
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, D, false>), dim3((unsigned)nk), dim3(256), 0, s, Q, K, V, dO, lse2, delta,
+        launch_kernel((attn_bwd_dkv_kernel<T, D, false>), dim3((unsigned)nk), dim3(256), 0, s, Q, K, V, dO, lse2, delta,
                            static_cast<T*>(dk), static_cast<T*>(dv), (int)N, (int)nkblk, (int)nk, scale);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, false>), dim3((unsigned)nq), dim3(512), 0, s, Q, K, V, dO, lse, delta,
+        launch_kernel((attn_bwd_dq_kernel<T, D, false>), dim3((unsigned)nq), dim3(512), 0, s, Q, K, V, dO, lse, delta,
                            static_cast<T*>(dq), (int)N, (int)nqblk, (int)nq, scale);
     }
     return check_launch("attn_bwd_mfma");

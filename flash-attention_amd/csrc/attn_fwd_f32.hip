@@ -295,7 +295,7 @@ int launch(const float* q, const float* k, const float* v, float* o, float* lse,
             return fail(MYFA_E_LAUNCH, "attention (f32): cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
     }
     const dim3 grid((unsigned)cdiv(qgroups, qgn), (unsigned)heads);
-    hipLaunchKernelGGL(kern, grid, dim3(qgn * ks * 64), lds_bytes, s, q, k, v, o, lse, (int)N, (int)d,
+    launch_kernel(kern, grid, dim3(qgn * ks * 64), lds_bytes, s, q, k, v, o, lse, (int)N, (int)d,
                        qgn, ks, (long long)(N * d), scale);
     return check_launch("attn_fwd_f32");
 }

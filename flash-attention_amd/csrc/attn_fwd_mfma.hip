@@ -32,8 +32,7 @@
 //   K tile [64][D]: 16-byte chunk c of row r at  r*2D + 16*(c ^ swzK(r))   (ds_read_b128 rows)
 //   V tile [64][D]: chunk c of row r at          r*2D + 16*(c ^ swzV(r))   (transposing reads)
 #include "attn_mfma_common.h"
-
-#include <cstdlib>
+#include "tuning.h"
 
 namespace myfa {
 namespace {
@@ -464,12 +463,14 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
                     if (key >= N || (CAUSAL && key > qrow)) s[kb][i] = -INFINITY;
                 }
         }
-        float tmax = s[0][0];
+        // row max: two independent chains of v_max3_f32 written out as single instructions (fmaxf
+        // would first quiet a possible signalling NaN in each chain head), then the other half's
+        float a = vmax3(s[0][0], s[0][1], s[0][2]), b = vmax3(s[1][0], s[1][1], s[1][2]);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, s[kb][i]);
-        const float mt = half_exchange_max(tmax) * sl2;
+        for (int i = 3; i < 15; i += 2) { a = vmax3(a, s[0][i], s[0][i + 1]); b = vmax3(b, s[1][i], s[1][i + 1]); }
+        const HalfPair hp = both_halves(vmax3(a, b, vmax2(s[0][15], s[1][15])));
+        const float tmax = vmax2(hp.lo, hp.hi);
+        const float mt = tmax * sl2;
         if constexpr (STAMP) s1 = stamp();
         if (__builtin_amdgcn_ballot_w64(mt - m > thr) != 0) {   // wave-uniform
             const float m_new = fmaxf(m, mt);
@@ -661,19 +662,6 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
 
 }
 
-// Benchmark-only knobs, read at every launch so one process can A/B them:
-// MYFA_ATTN_VARIANT (0 = one-barrier loop, 1 = ping-pong, the default) and
-// MYFA_ATTN_THR (deferred-max threshold in log2 units, default 8; 0 = rescale whenever a max grows).
-struct Tuning { int variant; float thr; unsigned long long* dbg; };
-Tuning tuning() {
-    Tuning x{1, 8.f, nullptr};
-    // MYFA_ATTN_DBG = device address (decimal) of a 24 * nwg u64 buffer: selects the stamped build
-    if (const char* e = std::getenv("MYFA_ATTN_DBG")) x.dbg = reinterpret_cast<unsigned long long*>(std::strtoull(e, nullptr, 10));
-    if (const char* e = std::getenv("MYFA_ATTN_VARIANT")) x.variant = std::atoi(e);
-    if (const char* e = std::getenv("MYFA_ATTN_THR")) x.thr = (float)std::atof(e);
-    return x;
-}
-
 template <typename T, int D>
 int launch(const void* q, const void* k, const void* v, void* o, float* lse,
            int64_t heads, int64_t N, float scale, bool causal, hipStream_t s) {
@@ -681,20 +669,23 @@ int launch(const void* q, const void* k, const void* v, void* o, float* lse,
     const int64_t nwg = heads * nqblk;
     if (nwg > 0x7fffffffLL) return fail(MYFA_E_UNSUPPORTED, "attention: too many workgroups (%lld)", (long long)nwg);
     const float sl2 = scale * 1.4426950408889634f;
-    const Tuning tn = tuning();
-    if (tn.variant == 0 && !causal)
-        hipLaunchKernelGGL((attn_fwd_mfma_kernel<T, D>), dim3((unsigned)nwg), dim3(kThreads), 0, s,
+    const Tuning& tn = tuning();
+    if (tn.attn_variant == 0 && !causal)
+        launch_kernel((attn_fwd_mfma_kernel<T, D>), dim3((unsigned)nwg), dim3(kThreads), 0, s,
                            static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
                            static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2);
     else {
         auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kThreads), 0, s,
+            launch_kernel(kern, dim3((unsigned)nwg), dim3(kThreads), 0, s,
                                static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
-                               static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, tn.thr, tn.dbg);
+                               static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, tn.attn_thr, tn.attn_dbg);
         };
-        if (causal && tn.dbg != nullptr) go(attn_fwd_mfma_pp_kernel<T, D, true, true>);
-        else if (causal) go(attn_fwd_mfma_pp_kernel<T, D, false, true>);
-        else if (tn.dbg != nullptr) go(attn_fwd_mfma_pp_kernel<T, D, true>);
+#ifdef MYFA_TUNING
+        if (causal && tn.attn_dbg != nullptr) go(attn_fwd_mfma_pp_kernel<T, D, true, true>);
+        else if (tn.attn_dbg != nullptr) go(attn_fwd_mfma_pp_kernel<T, D, true>);
+        else
+#endif
+        if (causal) go(attn_fwd_mfma_pp_kernel<T, D, false, true>);
         else go(attn_fwd_mfma_pp_kernel<T, D, false>);
     }
     return check_launch("attn_fwd_mfma");
@@ -702,11 +693,21 @@ int launch(const void* q, const void* k, const void* v, void* o, float* lse,
 
 }  // namespace
 
+int attn_fwd_mfma16(const void* q, const void* k, const void* v, void* o, float* lse,
+                    int64_t heads, int64_t N, int64_t d, float scale, float thr, int dtype, bool causal, hipStream_t s);
+
 // dtype: MYFA_F16 or MYFA_BF16; d: 64 or 128; heads = B*H
 int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* lse,
                   int64_t heads, int64_t N, int64_t d, float scale, int dtype, bool causal, hipStream_t s) {
     if (!(scale > 0.f)) return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16): scale must be > 0, got %g", (double)scale);
     if (N > 0x7fffffffLL / 256) return fail(MYFA_E_UNSUPPORTED, "attention: N=%lld too large", (long long)N);
+    // The 16x16x32 build is the default without a mask: the chip holds a higher clock on that MFMA
+    // shape (random operands; measured +6..12 % at d = 128, +2 % at d = 64).  Under the causal mask
+    // the 32x32x16 build is the faster one (its workgroups spend more of their time outside the
+    // tile loop, and the mask costs the 16x16x32 build more).
+    const int variant = tuning().attn_variant;
+    if (variant == 2 || (variant < 0 && !causal))
+        return attn_fwd_mfma16(q, k, v, o, lse, heads, N, d, scale, tuning().attn_thr, dtype, causal, s);
     if (dtype == MYFA_BF16 && d == 128) return launch<__bf16, 128>(q, k, v, o, lse, heads, N, scale, causal, s);
     if (dtype == MYFA_BF16 && d == 64)  return launch<__bf16, 64>(q, k, v, o, lse, heads, N, scale, causal, s);
     if (dtype == MYFA_F16 && d == 128)  return launch<_Float16, 128>(q, k, v, o, lse, heads, N, scale, causal, s);

@@ -99,6 +99,24 @@ __device__ __forceinline__ float half_exchange_sum(float x) {
     return p.lo + p.hi;
 }
 
+// Maxima of values that come straight out of MFMA accumulators, as single instructions.  fmaxf()
+// on such a value first quiets a possible signalling NaN (v_max_f32 x, x, x) because the compiler
+// cannot know the value is canonical; these do not, and a NaN input gives the other operand,
+// as the hardware's v_max does.
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+struct RawMaxOp {
+    __device__ __forceinline__ float operator()(float a, float b) const { return vmax2(a, b); }
+};
+
 // LDS image of a [rows][D] 16-bit tile made of 8-row x 64-byte subtiles (c = 16-byte chunk of
 // the row).  Row reads (ds_read_b128: row = lane & 31, chunk 2*kstep + (lane >> 5)) and
 // transposing reads (ds_read_b64_tr_b16) are both bank-conflict-free on it.

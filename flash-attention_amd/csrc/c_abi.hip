@@ -3,10 +3,12 @@
 // Replaces the argument checking / dispatch half of the reference's binding
 // layer (csrc/api.cpp:110-192); output allocation stays with the caller.
 #include "myfa_common.h"
+#include "tuning.h"
 
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <string>
 
 namespace myfa {
 
@@ -22,11 +24,21 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+thread_local hipError_t t_launch_err = hipSuccess;
+
 int check_launch(const char* what) {
-    const hipError_t e = hipGetLastError();
+    const hipError_t e = t_launch_err;
+    t_launch_err = hipSuccess;
     if (e != hipSuccess) return fail(MYFA_E_LAUNCH, "%s: launch failed: %s", what, hipGetErrorString(e));
     return MYFA_OK;
 }
+
+#ifdef MYFA_TUNING
+Tuning& tuning() {
+    static Tuning t{};
+    return t;
+}
+#endif
 
 // implemented in the kernel translation units
 int softmax_f32(const float* in, float* out, int64_t h, int64_t w, hipStream_t s);
@@ -168,5 +180,34 @@ int myfa_attn_bwd_bhnd_static_ws(const void* q, const void* k, const void* v, co
 int myfa_matmul_f32(const float* a, const float* b, float* c, int64_t m, int64_t k, int64_t n, void* stream) {
     return matmul_f32(a, b, c, m, k, n, static_cast<hipStream_t>(stream));
 }
+
+#ifdef MYFA_TUNING
+// Exported by the tuning flavour only (not part of include/myfa.h).  Keys: attn_variant,
+// attn_thr, attn_bq, matmul_block, softmax_tpr, softmax_v, softmax_map, softmax_nt, softmax_pad,
+// reset (back to the defaults).  Returns 0, or 1 for an unknown key.
+int myfa_tuning_set(const char* key, double value) {
+    Tuning& t = tuning();
+    const std::string k(key ? key : "");
+    if (k == "reset") t = Tuning{};
+    else if (k == "attn_variant") t.attn_variant = (int)value;
+    else if (k == "attn_thr") t.attn_thr = (float)value;
+    else if (k == "attn_bq") t.attn_bq = (int)value;
+    else if (k == "matmul_block") t.matmul_block = (int)value;
+    else if (k == "softmax_tpr") t.softmax_shape[0] = (int)value;
+    else if (k == "softmax_v") t.softmax_shape[1] = (int)value;
+    else if (k == "softmax_map") t.softmax_shape[2] = (int)value;
+    else if (k == "softmax_nt") t.softmax_shape[3] = (int)value;
+    else if (k == "softmax_pad") t.softmax_shape[4] = (int)value;
+    else return fail(MYFA_E_INVALID, "tuning: unknown key '%s'", k.c_str());
+    return MYFA_OK;
+}
+// attn_dbg: device buffer of 24 u64 per workgroup for the stamped attention build (NULL: off)
+int myfa_tuning_set_ptr(const char* key, void* p) {
+    const std::string k(key ? key : "");
+    if (k == "attn_dbg") tuning().attn_dbg = static_cast<unsigned long long*>(p);
+    else return fail(MYFA_E_INVALID, "tuning: unknown pointer key '%s'", k.c_str());
+    return MYFA_OK;
+}
+#endif
 
 }  // extern "C"

@@ -13,8 +13,8 @@
 // ones are multiplied.  Large problems (512 or more 128 x 128 blocks): sgemm_mfma_128_kernel
 // below.  Any m, k, n: edges are zero-filled on the way in and skipped on the way out.
 #include "myfa_common.h"
+#include "tuning.h"
 
-#include <cstdlib>
 
 namespace myfa {
 namespace {
@@ -266,18 +266,18 @@ int matmul_f32(const float* a, const float* b, float* c, int64_t m, int64_t k, i
     // (the vector path's 32-bit buffer offsets cover 128 rows of A and 16 rows of B)
     const bool vec = k % 4 == 0 && n % 4 == 0 && k <= (1 << 21) && n <= (1 << 24) &&
                      ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) % 16 == 0);
-    // 128 x 128 blocks once they fill the chip twice over; MYFA_MATMUL_BLOCK=64|128 forces a kernel (benchmarks only)
-    const char* force = std::getenv("MYFA_MATMUL_BLOCK");
-    const bool large = force ? std::atoi(force) == 128 : cdiv(n, kLN) * cdiv(m, kLM) >= 512;
+    // 128 x 128 blocks once they fill the chip twice over (the tuning flavour of the library can force either kernel)
+    const int force = tuning().matmul_block;
+    const bool large = force ? force == 128 : cdiv(n, kLN) * cdiv(m, kLM) >= 512;
     if (large) {
         const dim3 g128((unsigned)cdiv(n, kLN), (unsigned)cdiv(m, kLM));
-        if (vec) hipLaunchKernelGGL(sgemm_mfma_128_kernel<true>, g128, dim3(256), 0, s, a, b, c, (int)m, (int)k, (int)n);
-        else     hipLaunchKernelGGL(sgemm_mfma_128_kernel<false>, g128, dim3(256), 0, s, a, b, c, (int)m, (int)k, (int)n);
+        if (vec) launch_kernel(sgemm_mfma_128_kernel<true>, g128, dim3(256), 0, s, a, b, c, (int)m, (int)k, (int)n);
+        else     launch_kernel(sgemm_mfma_128_kernel<false>, g128, dim3(256), 0, s, a, b, c, (int)m, (int)k, (int)n);
         return check_launch("matmul_f32");
     }
     const dim3 grid((unsigned)cdiv(n, kBN), (unsigned)cdiv(m, kBM));
-    if (vec) hipLaunchKernelGGL(sgemm_mfma_kernel<true>, grid, dim3(256), 0, s, a, b, c, (int)m, (int)k, (int)n);
-    else     hipLaunchKernelGGL(sgemm_mfma_kernel<false>, grid, dim3(256), 0, s, a, b, c, (int)m, (int)k, (int)n);
+    if (vec) launch_kernel(sgemm_mfma_kernel<true>, grid, dim3(256), 0, s, a, b, c, (int)m, (int)k, (int)n);
+    else     launch_kernel(sgemm_mfma_kernel<false>, grid, dim3(256), 0, s, a, b, c, (int)m, (int)k, (int)n);
     return check_launch("matmul_f32");
 }
 

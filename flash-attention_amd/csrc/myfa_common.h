@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <tuple>
+#include <utility>
+
 #include "myfa.h"
 
 namespace myfa {
@@ -11,8 +14,23 @@ namespace myfa {
 // Records a message for myfa_last_error() and returns `code`.
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 
-// Peeks at the launch status of the kernel just enqueued (no synchronisation).
+// Kernel launches go through launch_kernel(): it keeps the status hipLaunchKernel returns for THIS
+// launch.  (hipGetLastError() after a <<<>>> launch reads and clears the thread's sticky error
+// slot, which may hold an error some earlier HIP call of the process left there; the library
+// never touches that slot.)  check_launch() reports the first failed launch since the previous
+// check_launch() on this thread, without synchronising.
+extern thread_local hipError_t t_launch_err;
 int check_launch(const char* what);
+
+template <typename... KArgs, typename... Args>
+inline void launch_kernel(void (*kern)(KArgs...), dim3 grid, dim3 block, unsigned lds_bytes, hipStream_t s, Args&&... args) {
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel argument count");
+    std::tuple<KArgs...> vals(static_cast<KArgs>(std::forward<Args>(args))...);
+    void* ptrs[sizeof...(KArgs) ? sizeof...(KArgs) : 1];
+    std::apply([&](auto&... v) { int i = 0; ((ptrs[i++] = (void*)&v), ...); }, vals);
+    const hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(kern), grid, block, ptrs, lds_bytes, s);
+    if (e != hipSuccess && t_launch_err == hipSuccess) t_launch_err = e;
+}
 
 constexpr int kWave = 64;  // CDNA wavefront width
 

@@ -202,8 +202,8 @@ void launch_cols(const E* in, E* out, int64_t outer, int64_t len, int64_t inner,
     if ((TXV == 4 ? (items <= 4 || small) : items > TXV / 2) && cdiv(len, (int64_t)(256 / TXV)) <= RMAX && (small || blocks(TXV) >= 512 || TXV == 4)) { \
         const int64_t nchunk = cdiv(items, (int64_t)TXV); \
         const dim3 g((unsigned)blocks(TXV)), b(256); \
-        if (cdiv(len, (int64_t)(256 / TXV)) <= RMAX / 4) hipLaunchKernelGGL((softmax_cols_reg<E, TXV, VW, RMAX / 4>), g, b, 0, s, in, out, len, inner, nchunk); \
-        else hipLaunchKernelGGL((softmax_cols_reg<E, TXV, VW, RMAX>), g, b, 0, s, in, out, len, inner, nchunk); \
+        if (cdiv(len, (int64_t)(256 / TXV)) <= RMAX / 4) launch_kernel((softmax_cols_reg<E, TXV, VW, RMAX / 4>), g, b, 0, s, in, out, len, inner, nchunk); \
+        else launch_kernel((softmax_cols_reg<E, TXV, VW, RMAX>), g, b, 0, s, in, out, len, inner, nchunk); \
         return; \
     }
     MYFA_REG(64) MYFA_REG(16) MYFA_REG(8) MYFA_REG(4)
@@ -214,8 +214,8 @@ void launch_cols(const E* in, E* out, int64_t outer, int64_t len, int64_t inner,
     if (LAST || (items > TXV / 2 && blocks(TXV) >= 256)) { \
         const int64_t nchunk = cdiv(items, (int64_t)TXV); \
         const dim3 g((unsigned)blocks(TXV)); \
-        if (big) hipLaunchKernelGGL((softmax_cols_stream<E, TXV, VW, BIG>), g, dim3(BIG), 0, s, in, out, len, inner, nchunk); \
-        else hipLaunchKernelGGL((softmax_cols_stream<E, TXV, VW, 256>), g, dim3(256), 0, s, in, out, len, inner, nchunk); \
+        if (big) launch_kernel((softmax_cols_stream<E, TXV, VW, BIG>), g, dim3(BIG), 0, s, in, out, len, inner, nchunk); \
+        else launch_kernel((softmax_cols_stream<E, TXV, VW, 256>), g, dim3(256), 0, s, in, out, len, inner, nchunk); \
         return; \
     }
     MYFA_STREAM(64, false) MYFA_STREAM(16, false) MYFA_STREAM(8, items >= 8) MYFA_STREAM(4, true)

@@ -1,0 +1,43 @@
+// Tuning knobs of the launchers.
+//
+// The shipped library (libmyfa_gfx950.so) has none: tuning() returns compile-time defaults and
+// reads nothing from the process environment.  The -DMYFA_TUNING flavour
+// (libmyfa_gfx950_tuning.so, used by tools/ and by the tests that compare kernel variants)
+// keeps one mutable record per process and exports two extra C symbols to set it,
+// myfa_tuning_set(key, value) and myfa_tuning_set_ptr(key, pointer); both flavours export the
+// same ABI otherwise.
+#ifndef MYFA_TUNING_H_
+#define MYFA_TUNING_H_
+
+namespace myfa {
+
+struct Tuning {
+    // attention forward, f16/bf16:
+    //   0 = 32x32x16 MFMA, one barrier per tile, register-staged K/V
+    //   1 = 32x32x16 MFMA, ping-pong of the two waves of a SIMD, LDS-DMA rings
+    //   2 = 16x16x32 MFMA, same schedule as 1
+    //  -1 = the library's choice per shape
+    int attn_variant = -1;
+    // deferred-max threshold in log2 units (0 = rescale whenever a row max grows: the textbook recurrence)
+    float attn_thr = 8.f;
+    // query rows per workgroup for the ping-pong kernels: 0 = library's choice, else 128 or 256
+    int attn_bq = 0;
+    // device buffer for the stamped (cycle-counting) diagnostic build, 24 u64 per workgroup
+    unsigned long long* attn_dbg = nullptr;
+    // row softmax launch shape override: threads per row, items per thread, map, nt, pad (tpr = 0: none)
+    int softmax_shape[5] = {0, 0, 0, 3, 0};
+    // float32 matmul block edge: 0 = library's choice, 64 or 128
+    int matmul_block = 0;
+};
+
+#ifdef MYFA_TUNING
+Tuning& tuning();
+#else
+inline const Tuning& tuning() {
+    static const Tuning t{};
+    return t;
+}
+#endif
+
+}  // namespace myfa
+#endif  // MYFA_TUNING_H_

@@ -8,7 +8,10 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmyfa_gfx950.so")
+# MYFA_LIBRARY names another build of the same ABI (tools/ use it to load the tuning flavour,
+# libmyfa_gfx950_tuning.so); the ABI version check below applies to it all the same.
+LIB_PATH = os.environ.get("MYFA_LIBRARY") or os.path.join(_HERE, "libmyfa_gfx950.so")
+TUNING_LIB_PATH = os.path.join(_HERE, "libmyfa_gfx950_tuning.so")
 
 ABI_VERSION = 1
 MYFA_F32, MYFA_F16, MYFA_BF16 = 0, 1, 2

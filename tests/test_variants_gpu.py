@@ -1,0 +1,116 @@
+"""GPU parity tests of the kernel variants the launchers choose between.
+
+The shipped library takes no knobs; its tuning flavour (libmyfa_gfx950_tuning.so, the same
+sources with -DMYFA_TUNING) can force a variant.  Every variant must meet the oracle on its
+own: the two MFMA shapes of the f16/bf16 attention forward (32x32x16 and 16x16x32), the
+one-barrier schedule, the deferred-max threshold (0 = the textbook recurrence of the
+reference's Python statement, tests/test_flash_attn.py:82-93), and both block sizes of the
+float32 matmul (the reference's my_matmul, csrc/my_flash_attn/matmul.cu:22-50).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from oracle import ref_cpu
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.gpu
+
+LP_ATOL = 2e-2
+
+
+@pytest.fixture(scope="module")
+def tuned():
+    from tuned import Tuned
+    assert torch.cuda.is_available()
+    t = Tuned()
+    yield t
+    t.set()
+
+
+def _rounded(x, dtype):
+    return x.to(dtype).float().numpy()
+
+
+def _maxdiff(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+
+
+VARIANTS = [dict(attn_variant=1, attn_thr=0), dict(attn_variant=1, attn_thr=8), dict(attn_variant=0),
+            dict(attn_variant=2, attn_thr=0), dict(attn_variant=2, attn_thr=8)]
+
+
+@pytest.mark.parametrize("knobs", VARIANTS, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
+@pytest.mark.parametrize("dtype,d", [(torch.bfloat16, 128), (torch.float16, 64), (torch.float16, 128), (torch.bfloat16, 64)])
+def test_schedules_shapes_and_deferred_max_agree(tuned, knobs, dtype, d):
+    """Random data plus keys that force large, late jumps of single rows' max."""
+    tuned.set(**knobs)
+    torch.manual_seed(1)
+    N = 1000
+    q, k, v = (torch.randn(2, 2, N, d) for _ in range(3))
+    for row, key in [(0, 130), (5, 999), (15, 3), (16, 700), (31, 64), (32, 65), (100, 300), (255, 575), (256, 1), (999, 998)]:
+        k[:, :, key] = q[:, :, row] * 3.0
+    out, lse = tuned.flash_attn_fwd(q.cuda().to(dtype), k.cuda().to(dtype), v.cuda().to(dtype), scale=1.0, return_lse=True)
+    qr, kr, vr = (_rounded(x, dtype) for x in (q, k, v))
+    assert _maxdiff(out.float().cpu().numpy(), ref_cpu.attention_bhnd(qr, kr, vr, scale=1.0)) <= LP_ATOL
+    assert _maxdiff(lse.cpu().numpy(), ref_cpu.attention_lse(qr, kr, scale=1.0)) <= 2e-3
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [
+    (1, 1, 64, 64), (1, 1, 1, 64), (2, 3, 200, 64), (1, 3, 1025, 64), (1, 2, 256, 128),
+    (1, 2, 257, 128), (1, 1, 63, 128), (2, 2, 1000, 128), (1, 5, 511, 128), (3, 1, 320, 64),
+])
+def test_mfma_shapes_vs_oracle(tuned, variant, causal, dtype, shape):
+    B, H, N, d = shape
+    scale = d ** -0.5
+    tuned.set(attn_variant=variant)
+    torch.manual_seed(1)
+    q, k, v = (torch.randn(B, H, N, d, dtype=torch.float32) for _ in range(3))
+    out, lse = tuned.flash_attn_fwd(q.cuda().to(dtype), k.cuda().to(dtype), v.cuda().to(dtype),
+                                    scale=scale, causal=causal, return_lse=True)
+    qr, kr, vr = (_rounded(x, dtype) for x in (q, k, v))
+    ref = ref_cpu.attention_bhnd(qr, kr, vr, scale=scale, causal=causal)
+    assert bool(torch.isfinite(out.float()).all())
+    assert _maxdiff(out.float().cpu().numpy(), ref) <= LP_ATOL
+    assert _maxdiff(lse.cpu().numpy(), ref_cpu.attention_lse(qr, kr, scale=scale, causal=causal)) <= 1e-3
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_memory_behind_the_tensors_never_reaches_the_output(tuned, variant):
+    """Fetches past the end of K/V must come back as zeros (buffer bounds), never as the NaNs
+    planted behind the tensors."""
+    tuned.set(attn_variant=variant)
+    B, H, N, d, dtype = 1, 2, 100, 128, torch.bfloat16
+    torch.manual_seed(1)
+    n = B * H * N * d
+    bufs = [torch.full((n + 64 * 1024,), float("nan"), dtype=dtype, device="cuda") for _ in range(3)]
+    host = [torch.randn(B, H, N, d, dtype=torch.float32) for _ in range(3)]
+    views = []
+    for b, x in zip(bufs, host):
+        b[:n] = x.reshape(-1).to(dtype).cuda()
+        views.append(b[:n].view(B, H, N, d))
+    out = tuned.flash_attn_fwd(*views, scale=d ** -0.5)
+    assert bool(torch.isfinite(out.float()).all())
+    qr, kr, vr = (_rounded(x, dtype) for x in host)
+    assert _maxdiff(out.float().cpu().numpy(), ref_cpu.attention_bhnd(qr, kr, vr, scale=d ** -0.5)) <= LP_ATOL
+
+
+@pytest.mark.parametrize("block", [64, 128])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (3, 7, 11), (128, 16, 128), (129, 17, 131), (260, 36, 132), (100, 200, 300),
+                                   (256, 4, 512), (130, 1000, 4), (512, 520, 388)])
+def test_matmul_both_kernels_small_shapes(tuned, block, shape):
+    """Both block sizes forced on ragged and aligned shapes (vector and scalar staging)."""
+    tuned.set(matmul_block=block)
+    h, k, w = shape
+    torch.manual_seed(2)
+    a, b = torch.randn(h, k, device="cuda"), torch.randn(k, w, device="cuda")
+    ref = (a.double() @ b.double()).float()
+    assert torch.isclose(tuned.my_matmul(a, b), ref, atol=1e-4, rtol=1e-5).all()

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Diagnostic: per-phase cycle shares of the ping-pong attention kernel (stamped build)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "flash-attention_amd"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from tuned import Tuned
 import torch
-import my_flash_attn_cuda as mfa
+mfa = Tuned()
 args = dict(kv.split("=") for kv in sys.argv[1:])
 B, H, N, d = map(int, args.pop("shape", "4,32,4096,128").split(","))
 torch.manual_seed(1)
@@ -12,9 +12,7 @@ q, k, v = (torch.randn(B, H, N, d, dtype=torch.bfloat16, device="cuda") for _ in
 nwg = B * H * (N // 256)
 dbg = torch.zeros(nwg * 24, dtype=torch.int64, device="cuda")
 causal = bool(int(args.pop("causal", "0")))
-for key, val in args.items():
-    os.environ["MYFA_ATTN_" + key] = val
-os.environ["MYFA_ATTN_DBG"] = str(dbg.data_ptr())
+mfa.set(attn_dbg=dbg.data_ptr(), **{key: float(val) for key, val in args.items()})
 for _ in range(3):
     mfa.flash_attn_fwd(q, k, v, scale=d ** -0.5, causal=causal)
 torch.cuda.synchronize()
