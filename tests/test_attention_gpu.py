@@ -252,6 +252,14 @@ def test_config5_shard_bf16(mfa, c_oracle):
     assert worst <= LP_ATOL
 
 
+def test_config5_full_single_gpu(mfa, c_oracle):
+    """The scaling configuration whole on one GPU (its 1-GPU point): bf16, B=8 H=32 N=16384 d=128,
+    256 heads = 16384 workgroups, 1 GiB per tensor; sampled rows of three heads against all keys."""
+    *_, worst = _sampled_check(mfa, c_oracle, 8, 32, 16384, 128, torch.bfloat16, 128 ** -0.5,
+                               heads=[(0, 0), (4, 13), (7, 31)], nrows=24)
+    assert worst <= LP_ATOL
+
+
 def test_nondefault_stream_and_reuse(mfa):
     torch.manual_seed(1)
     q, k, v = (torch.randn(2, 4, 512, 128, dtype=torch.bfloat16, device="cuda") for _ in range(3))

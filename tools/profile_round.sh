@@ -4,7 +4,7 @@
 # a plain full bench run, and the PMC passes of the headline attention kernel.  Run on the GPU box from the repo root:
 #   bash tools/profile_round.sh <tag>
 set -u
-tag=${1:-r01}
+tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_$tag
 mkdir -p "$out"
@@ -18,7 +18,7 @@ rc=$?; echo "plain bench rc=$rc"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/full" -o bench -- python3 bench.py > "$out/full_bench_under_rocprof.json" 2> "$out/full_bench_under_rocprof.err"
 rc=$?; echo "full bench under rocprofv3 rc=$rc"
 [ $rc -ne 0 ] && { tail -5 "$out/full_bench_under_rocprof.err"; exit $rc; }
-bash tools/pmc_attn.sh "$tag" "VARIANT=1" > "$out/attn_headline_pmc.txt" 2>&1
+bash tools/pmc_attn.sh "$tag" "attn_variant=-1" > "$out/attn_headline_pmc.txt" 2>&1
 rc=$?; echo "pmc rc=$rc"; tail -3 "$out/attn_headline_pmc.txt"
 find "$out" -name "*kernel_stats.csv" | head
 exit $rc
