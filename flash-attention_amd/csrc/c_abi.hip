@@ -44,6 +44,8 @@ Tuning& tuning() {
 int softmax_f32(const float* in, float* out, int64_t h, int64_t w, hipStream_t s);
 int softmax_rows(const void* in, void* out, int64_t h, int64_t w, int dtype, hipStream_t s);
 int softmax_strided(const void* in, void* out, int64_t outer, int64_t len, int64_t inner, int dtype, hipStream_t s);
+int softmax_strided_pro(const void* in, void* out, int64_t outer, int64_t len, int64_t inner, int dtype,
+                        float scale, const float* mask, int64_t mask_outer, bool causal, hipStream_t s);
 int matmul_f32(const float* a, const float* b, float* c, int64_t m, int64_t k, int64_t n, hipStream_t s);
 int attn_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse,
                  int64_t heads, int64_t N, int64_t d, int64_t k_key_stride, int64_t k_d_stride,
@@ -91,6 +93,13 @@ int myfa_softmax(const void* in, void* out, int64_t h, int64_t w, int dtype, voi
 
 int myfa_softmax_nd(const void* in, void* out, int64_t outer, int64_t len, int64_t inner, int dtype, void* stream) {
     return softmax_strided(in, out, outer, len, inner, dtype, static_cast<hipStream_t>(stream));
+}
+
+int myfa_softmax_nd_ex(const void* in, void* out, int64_t outer, int64_t len, int64_t inner, int dtype,
+                       float scale, const float* add_mask, int64_t mask_outer, int flags, void* stream) {
+    if ((flags & ~MYFA_SOFTMAX_CAUSAL) != 0) return fail(MYFA_E_INVALID, "softmax: unknown flag bits 0x%x", flags);
+    return softmax_strided_pro(in, out, outer, len, inner, dtype, scale, add_mask, mask_outer,
+                               (flags & MYFA_SOFTMAX_CAUSAL) != 0, static_cast<hipStream_t>(stream));
 }
 
 int myfa_attn_fwd_f32(const float* q, const float* k_t, const float* v, float* o,

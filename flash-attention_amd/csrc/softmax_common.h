@@ -4,6 +4,17 @@
 #include "myfa_common.h"
 
 namespace myfa {
+
+// Fused prologue: the softmax is taken of  scale * x + mask  (and, with causal_rows, keys after
+// the row's query hidden).  Kernels carry it behind a template flag PRO; with PRO = false the
+// record is ignored and the code is the plain softmax.
+struct Prologue {
+    float scale = 1.f;            // multiplies every element first
+    const float* mask = nullptr;  // additive float32 [mask_outer, len, inner]; slice o % mask_outer serves outer index o
+    int64_t mask_outer = 1;
+    int64_t causal_rows = 0;      // > 0 (inner == 1 only): outer index o is query o % causal_rows, keys j > query -> -inf
+};
+
 namespace {
 
 constexpr float kLog2e = 1.4426950408889634f;
@@ -38,6 +49,37 @@ __device__ __forceinline__ void vstore(E* p, const float (&src)[VW]) {
         for (int c = 0; c < VW; ++c) t[c] = (E)src[c];
         if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<P*>(p));
         else *reinterpret_cast<P*>(p) = t;
+    }
+}
+
+// x[0..VW) = elements j .. j+VW-1 along the softmax dimension of outer index o (inner == 1)
+template <int VW>
+__device__ __forceinline__ void prologue_row(float (&x)[VW], const Prologue& p, int64_t o, int64_t len, int64_t j) {
+    if (p.mask != nullptr) {
+        const float* mrow = p.mask + (o % p.mask_outer) * len + j;
+#pragma unroll
+        for (int c = 0; c < VW; ++c) x[c] = __builtin_fmaf(x[c], p.scale, mrow[c]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < VW; ++c) x[c] *= p.scale;
+    }
+    if (p.causal_rows > 0) {
+        const int64_t qi = o % p.causal_rows;
+#pragma unroll
+        for (int c = 0; c < VW; ++c) if (j + c > qi) x[c] = -INFINITY;
+    }
+}
+
+// x[0..VW) = inner indices i .. i+VW-1 of row j (along the softmax dimension) of outer index o
+template <int VW>
+__device__ __forceinline__ void prologue_col(float (&x)[VW], const Prologue& p, int64_t o, int64_t len, int64_t inner, int64_t j, int64_t i) {
+    if (p.mask != nullptr) {
+        const float* m = p.mask + ((o % p.mask_outer) * len + j) * inner + i;
+#pragma unroll
+        for (int c = 0; c < VW; ++c) x[c] = __builtin_fmaf(x[c], p.scale, m[c]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < VW; ++c) x[c] *= p.scale;
     }
 }
 

@@ -39,9 +39,9 @@ __device__ __forceinline__ float rowgroup_reduce(float wave_val, float* slot, in
     }
 }
 
-template <typename E, int TPR, int V, int VW, int NTM = 3, int MAP = 0>
+template <typename E, int TPR, int V, int VW, int NTM = 3, int MAP = 0, bool PRO = false>
 __global__ void __launch_bounds__((TPR < 256 ? 256 : TPR))
-softmax_rows_reg(const E* __restrict__ in, E* __restrict__ out, int64_t h, int64_t w) {
+softmax_rows_reg(const E* __restrict__ in, E* __restrict__ out, int64_t h, int64_t w, Prologue pro) {
     constexpr int BLOCK = TPR < 256 ? 256 : TPR;
     constexpr int RPB = BLOCK / TPR;   // rows per workgroup
     constexpr int NW = TPR / 64;       // waves per row
@@ -72,6 +72,7 @@ softmax_rows_reg(const E* __restrict__ in, E* __restrict__ out, int64_t h, int64
         const int64_t col = item(v) * VW;
         if (col < w) {
             vload<E, VW, (NTM & 1) != 0>(x[v], src + col);
+            if constexpr (PRO) prologue_row<VW>(x[v], pro, row, w, col);
         } else {
 #pragma unroll
             for (int c = 0; c < VW; ++c) x[v][c] = -INFINITY;
@@ -106,9 +107,9 @@ softmax_rows_reg(const E* __restrict__ in, E* __restrict__ out, int64_t h, int64
 }
 
 // Rows too long to hold in registers: one 1024-thread workgroup per row.
-template <typename E, int VW>
+template <typename E, int VW, bool PRO = false>
 __global__ void __launch_bounds__(1024)
-softmax_rows_stream(const E* __restrict__ in, E* __restrict__ out, int64_t h, int64_t w) {
+softmax_rows_stream(const E* __restrict__ in, E* __restrict__ out, int64_t h, int64_t w, Prologue pro) {
     constexpr int T = 1024, NW = T / 64;
     __shared__ float scratch[NW];
     const int64_t row = blockIdx.x;
@@ -122,6 +123,7 @@ softmax_rows_stream(const E* __restrict__ in, E* __restrict__ out, int64_t h, in
     for (int64_t col = (int64_t)t * VW; col < w; col += (int64_t)T * VW) {
         float x[VW];
         vload<E, VW, false>(x, src + col);
+        if constexpr (PRO) prologue_row<VW>(x, pro, row, w, col);
         float cm = x[0];
 #pragma unroll
         for (int c = 1; c < VW; ++c) cm = fmaxf(cm, x[c]);
@@ -129,8 +131,13 @@ softmax_rows_stream(const E* __restrict__ in, E* __restrict__ out, int64_t h, in
             sum *= __builtin_amdgcn_exp2f((mx - cm) * kLog2e);  // mx = -inf first time: sum is 0
             mx = cm;
         }
+        // while everything this thread has seen is -inf there is nothing to add: (-inf) - (-inf) is
+        // NaN, and a NaN in `sum` would survive the later rescale by 0 (leading -inf elements of a
+        // row are ordinary input: left padding, sliding-window masks)
+        if (mx != -INFINITY) {
 #pragma unroll
-        for (int c = 0; c < VW; ++c) sum += __builtin_amdgcn_exp2f((x[c] - mx) * kLog2e);
+            for (int c = 0; c < VW; ++c) sum += __builtin_amdgcn_exp2f((x[c] - mx) * kLog2e);
+        }
     }
     const float row_mx = rowgroup_reduce<NW>(wave_max(mx), scratch, wave, MaxOp{});
     // threads that saw no element have mx = -inf, sum = 0: contribute 0
@@ -142,6 +149,7 @@ softmax_rows_stream(const E* __restrict__ in, E* __restrict__ out, int64_t h, in
     for (int64_t col = (int64_t)t * VW; col < w; col += (int64_t)T * VW) {
         float x[VW];
         vload<E, VW>(x, src + col);
+        if constexpr (PRO) prologue_row<VW>(x, pro, row, w, col);
 #pragma unroll
         for (int c = 0; c < VW; ++c)
             x[c] = __builtin_amdgcn_exp2f((x[c] - row_mx) * kLog2e) * inv;
@@ -155,25 +163,28 @@ softmax_rows_stream(const E* __restrict__ in, E* __restrict__ out, int64_t h, in
 //   pad : unused dynamic LDS, only there to cap the workgroups per CU
 struct Shape { int tpr, v, map, nt; unsigned pad; };
 
-template <typename E, int TPR, int V, int VW>
-void launch_reg(const E* in, E* out, int64_t h, int64_t w, hipStream_t s, const Shape& sh) {
+template <typename E, int TPR, int V, int VW, bool PRO>
+void launch_reg(const E* in, E* out, int64_t h, int64_t w, hipStream_t s, const Shape& sh, const Prologue& pro) {
     constexpr int BLOCK = TPR < 256 ? 256 : TPR;
     constexpr int RPB = BLOCK / TPR;
     const dim3 g((unsigned)cdiv(h, RPB)), b(BLOCK);
-    if constexpr (VW > 1) {
-        if (sh.map == 1 && sh.nt == 2) launch_kernel((softmax_rows_reg<E, TPR, V, VW, 2, 1>), g, b, sh.pad, s, in, out, h, w);
-        else if (sh.map == 1)          launch_kernel((softmax_rows_reg<E, TPR, V, VW, 3, 1>), g, b, sh.pad, s, in, out, h, w);
-        else if (sh.nt == 2)           launch_kernel((softmax_rows_reg<E, TPR, V, VW, 2, 0>), g, b, sh.pad, s, in, out, h, w);
-        else                           launch_kernel((softmax_rows_reg<E, TPR, V, VW, 3, 0>), g, b, sh.pad, s, in, out, h, w);
+    if constexpr (PRO) {
+        // one load/store policy and item map for the fused-prologue flavour (fewer builds)
+        launch_kernel((softmax_rows_reg<E, TPR, V, VW, 3, 0, true>), g, b, sh.pad, s, in, out, h, w, pro);
+    } else if constexpr (VW > 1) {
+        if (sh.map == 1 && sh.nt == 2) launch_kernel((softmax_rows_reg<E, TPR, V, VW, 2, 1, PRO>), g, b, sh.pad, s, in, out, h, w, pro);
+        else if (sh.map == 1)          launch_kernel((softmax_rows_reg<E, TPR, V, VW, 3, 1, PRO>), g, b, sh.pad, s, in, out, h, w, pro);
+        else if (sh.nt == 2)           launch_kernel((softmax_rows_reg<E, TPR, V, VW, 2, 0, PRO>), g, b, sh.pad, s, in, out, h, w, pro);
+        else                           launch_kernel((softmax_rows_reg<E, TPR, V, VW, 3, 0, PRO>), g, b, sh.pad, s, in, out, h, w, pro);
     } else {
-        launch_kernel((softmax_rows_reg<E, TPR, V, VW, 3, 0>), g, b, sh.pad, s, in, out, h, w);
+        launch_kernel((softmax_rows_reg<E, TPR, V, VW, 3, 0, PRO>), g, b, sh.pad, s, in, out, h, w, pro);
     }
 }
 
-template <typename E, int VW>
-bool dispatch_reg(const E* in, E* out, int64_t h, int64_t w, hipStream_t s, const Shape& sh) {
+template <typename E, int VW, bool PRO>
+bool dispatch_reg(const E* in, E* out, int64_t h, int64_t w, hipStream_t s, const Shape& sh, const Prologue& pro) {
 #define MYFA_CASE(T, VV) \
-    if (sh.tpr == T && sh.v == VV) { launch_reg<E, T, VV, VW>(in, out, h, w, s, sh); return true; }
+    if (sh.tpr == T && sh.v == VV) { launch_reg<E, T, VV, VW, PRO>(in, out, h, w, s, sh, pro); return true; }
     MYFA_CASE(64, 1) MYFA_CASE(64, 2) MYFA_CASE(64, 4) MYFA_CASE(64, 8)
     MYFA_CASE(256, 1) MYFA_CASE(256, 2) MYFA_CASE(256, 4) MYFA_CASE(256, 8)
     MYFA_CASE(512, 2) MYFA_CASE(512, 4) MYFA_CASE(512, 8)
@@ -216,8 +227,8 @@ Shape choose_shape(int64_t items, int64_t tensor_bytes, int vw) {
     return sh;
 }
 
-template <typename E>
-int softmax_any(const E* in, E* out, int64_t h, int64_t w, hipStream_t s) {
+template <typename E, bool PRO>
+int softmax_any(const E* in, E* out, int64_t h, int64_t w, const Prologue& pro, hipStream_t s) {
     if (h < 0 || w < 0) return fail(MYFA_E_INVALID, "softmax: negative size h=%lld w=%lld", (long long)h, (long long)w);
     if (h == 0 || w == 0) return MYFA_OK;
     if (!in || !out) return fail(MYFA_E_INVALID, "softmax: null pointer");
@@ -231,10 +242,10 @@ int softmax_any(const E* in, E* out, int64_t h, int64_t w, hipStream_t s) {
     if (const int* f = tuning().softmax_shape; f[0] > 0 && (int64_t)f[0] * f[1] * vw >= w)
         sh = Shape{f[0], f[1], f[2], f[3], (unsigned)f[4]};
     bool done = false;
-    if (sh.tpr) done = vec ? dispatch_reg<E, VWV>(in, out, h, w, s, sh) : dispatch_reg<E, 1>(in, out, h, w, s, sh);
+    if (sh.tpr) done = vec ? dispatch_reg<E, VWV, PRO>(in, out, h, w, s, sh, pro) : dispatch_reg<E, 1, PRO>(in, out, h, w, s, sh, pro);
     if (!done) {
-        if (vec) launch_kernel((softmax_rows_stream<E, VWV>), dim3((unsigned)h), dim3(1024), 0, s, in, out, h, w);
-        else     launch_kernel((softmax_rows_stream<E, 1>), dim3((unsigned)h), dim3(1024), 0, s, in, out, h, w);
+        if (vec) launch_kernel((softmax_rows_stream<E, VWV, PRO>), dim3((unsigned)h), dim3(1024), 0, s, in, out, h, w, pro);
+        else     launch_kernel((softmax_rows_stream<E, 1, PRO>), dim3((unsigned)h), dim3(1024), 0, s, in, out, h, w, pro);
     }
     return check_launch("softmax_rows");
 }
@@ -242,15 +253,26 @@ int softmax_any(const E* in, E* out, int64_t h, int64_t w, hipStream_t s) {
 }  // namespace
 
 int softmax_f32(const float* in, float* out, int64_t h, int64_t w, hipStream_t s) {
-    return softmax_any<float>(in, out, h, w, s);
+    return softmax_any<float, false>(in, out, h, w, Prologue{}, s);
 }
 
 // dtype: MYFA_F32, MYFA_F16 or MYFA_BF16 (element type of both tensors; arithmetic is float32)
 int softmax_rows(const void* in, void* out, int64_t h, int64_t w, int dtype, hipStream_t s) {
     switch (dtype) {
-        case MYFA_F32:  return softmax_any<float>(static_cast<const float*>(in), static_cast<float*>(out), h, w, s);
-        case MYFA_F16:  return softmax_any<_Float16>(static_cast<const _Float16*>(in), static_cast<_Float16*>(out), h, w, s);
-        case MYFA_BF16: return softmax_any<__bf16>(static_cast<const __bf16*>(in), static_cast<__bf16*>(out), h, w, s);
+        case MYFA_F32:  return softmax_any<float, false>(static_cast<const float*>(in), static_cast<float*>(out), h, w, Prologue{}, s);
+        case MYFA_F16:  return softmax_any<_Float16, false>(static_cast<const _Float16*>(in), static_cast<_Float16*>(out), h, w, Prologue{}, s);
+        case MYFA_BF16: return softmax_any<__bf16, false>(static_cast<const __bf16*>(in), static_cast<__bf16*>(out), h, w, Prologue{}, s);
+        default:        return fail(MYFA_E_INVALID, "softmax: unknown dtype tag %d", dtype);
+    }
+}
+
+// The same with the fused prologue (scale, additive mask, causal rows); pro.mask / pro.causal_rows
+// are indexed by the row number, so h is the `outer` of the [outer, len] view.
+int softmax_rows_pro(const void* in, void* out, int64_t h, int64_t w, int dtype, const Prologue& pro, hipStream_t s) {
+    switch (dtype) {
+        case MYFA_F32:  return softmax_any<float, true>(static_cast<const float*>(in), static_cast<float*>(out), h, w, pro, s);
+        case MYFA_F16:  return softmax_any<_Float16, true>(static_cast<const _Float16*>(in), static_cast<_Float16*>(out), h, w, pro, s);
+        case MYFA_BF16: return softmax_any<__bf16, true>(static_cast<const __bf16*>(in), static_cast<__bf16*>(out), h, w, pro, s);
         default:        return fail(MYFA_E_INVALID, "softmax: unknown dtype tag %d", dtype);
     }
 }

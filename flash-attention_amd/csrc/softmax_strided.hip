@@ -17,6 +17,7 @@
 
 namespace myfa {
 int softmax_rows(const void* in, void* out, int64_t h, int64_t w, int dtype, hipStream_t s);
+int softmax_rows_pro(const void* in, void* out, int64_t h, int64_t w, int dtype, const Prologue& pro, hipStream_t s);
 namespace {
 
 // Column statistics across the TY threads of a column: red is [TY][TX * VW] floats.
@@ -49,9 +50,9 @@ __device__ __forceinline__ void column_reduce(float (&v)[VW], float* red, int tx
     __syncthreads();   // red is reused by the next reduction
 }
 
-template <typename E, int TX, int VW, int R>
+template <typename E, int TX, int VW, int R, bool PRO = false>
 __global__ void __launch_bounds__(256)
-softmax_cols_reg(const E* __restrict__ in, E* __restrict__ out, int64_t len, int64_t inner, int64_t nchunk) {
+softmax_cols_reg(const E* __restrict__ in, E* __restrict__ out, int64_t len, int64_t inner, int64_t nchunk, Prologue pro) {
     constexpr int TY = 256 / TX;
     __shared__ float red[256 * VW];
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -69,6 +70,7 @@ softmax_cols_reg(const E* __restrict__ in, E* __restrict__ out, int64_t len, int
         const int64_t row = ty + (int64_t)r * TY;
         if (live && row < len) {
             vload<E, VW>(x[r], src + row * inner);
+            if constexpr (PRO) prologue_col<VW>(x[r], pro, o, len, inner, row, col);
         } else {
 #pragma unroll
             for (int c = 0; c < VW; ++c) x[r][c] = -INFINITY;
@@ -105,9 +107,9 @@ softmax_cols_reg(const E* __restrict__ in, E* __restrict__ out, int64_t len, int
 
 // Any len: BLOCK = 256, 512 or 1024 threads, rows taken U at a time per thread so that U loads are in
 // flight and the running max is refreshed once per U rows.
-template <typename E, int TX, int VW, int BLOCK>
+template <typename E, int TX, int VW, int BLOCK, bool PRO = false>
 __global__ void __launch_bounds__(BLOCK)
-softmax_cols_stream(const E* __restrict__ in, E* __restrict__ out, int64_t len, int64_t inner, int64_t nchunk) {
+softmax_cols_stream(const E* __restrict__ in, E* __restrict__ out, int64_t len, int64_t inner, int64_t nchunk, Prologue pro) {
     constexpr int TY = BLOCK / TX, U = VW == 8 ? 2 : 4;
     __shared__ float red[BLOCK * VW];
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -129,6 +131,7 @@ softmax_cols_stream(const E* __restrict__ in, E* __restrict__ out, int64_t len, 
                 const int64_t row = row0 + (int64_t)u * TY;
                 if (row < len) {
                     vload<E, VW, false>(x[u], src + row * inner);
+                    if constexpr (PRO) prologue_col<VW>(x[u], pro, o, len, inner, row, col);
                 } else {
 #pragma unroll
                     for (int c = 0; c < VW; ++c) x[u][c] = -INFINITY;
@@ -143,11 +146,14 @@ softmax_cols_stream(const E* __restrict__ in, E* __restrict__ out, int64_t len, 
                     sum[c] *= __builtin_amdgcn_exp2f((mx[c] - cm) * kLog2e);   // mx = -inf first time: sum is 0
                     mx[c] = cm;
                 }
-                // (rows past the end hold -inf and add 0; a column that is all -inf so far adds NaN,
-                // the value the definition gives it)
+                // rows past the end hold -inf and add 0.  While everything seen of a column is -inf
+                // there is nothing to add: (-inf) - (-inf) is NaN and would survive the later rescale
+                // by 0 (leading -inf rows are ordinary input: a causal mask along this dimension); only
+                // a column that is -inf throughout comes out NaN, through 0 * inf in the second pass
+                if (mx[c] != -INFINITY) {
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (u == 0 || row0 + (int64_t)u * TY < len) sum[c] += __builtin_amdgcn_exp2f((x[u][c] - mx[c]) * kLog2e);
+                    for (int u = 0; u < U; ++u) sum[c] += __builtin_amdgcn_exp2f((x[u][c] - mx[c]) * kLog2e);
+                }
             }
         }
     }
@@ -158,7 +164,7 @@ softmax_cols_stream(const E* __restrict__ in, E* __restrict__ out, int64_t len, 
     // threads that saw no row have mx = -inf, sum = 0: they contribute 0
 #pragma unroll
     for (int c = 0; c < VW; ++c)
-        sum[c] = (mx[c] == -INFINITY && sum[c] == 0.f) ? 0.f : sum[c] * __builtin_amdgcn_exp2f((mx[c] - cmx[c]) * kLog2e);
+        sum[c] = (mx[c] == -INFINITY) ? 0.f : sum[c] * __builtin_amdgcn_exp2f((mx[c] - cmx[c]) * kLog2e);
     column_reduce<TX, TY, VW>(sum, red, tx, ty, SumOp{});
 
     // pass 2: re-read (what is still in L2 / Infinity Cache comes from there) and write
@@ -170,7 +176,10 @@ softmax_cols_stream(const E* __restrict__ in, E* __restrict__ out, int64_t len, 
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t row = row0 + (int64_t)u * TY;
-                if (row < len) vload<E, VW>(x[u], src + row * inner);
+                if (row < len) {
+                    vload<E, VW>(x[u], src + row * inner);
+                    if constexpr (PRO) prologue_col<VW>(x[u], pro, o, len, inner, row, col);
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -192,8 +201,8 @@ softmax_cols_stream(const E* __restrict__ in, E* __restrict__ out, int64_t len, 
 //    that narrow.
 //  * Otherwise streamed: 1024 threads for long columns, the widest TX that leaves one workgroup
 //    per CU; never narrower than 8 items (128 bytes, an L2 line) when the row has them.
-template <typename E, int VW>
-void launch_cols(const E* in, E* out, int64_t outer, int64_t len, int64_t inner, hipStream_t s) {
+template <typename E, int VW, bool PRO>
+void launch_cols(const E* in, E* out, int64_t outer, int64_t len, int64_t inner, const Prologue& pro, hipStream_t s) {
     constexpr int RMAX = 64 / VW;      // at most 64 floats of column data per thread
     const int64_t items = cdiv(inner, (int64_t)VW);
     const bool small = outer * len * inner * (int64_t)sizeof(E) <= (8LL << 20);
@@ -202,8 +211,8 @@ void launch_cols(const E* in, E* out, int64_t outer, int64_t len, int64_t inner,
     if ((TXV == 4 ? (items <= 4 || small) : items > TXV / 2) && cdiv(len, (int64_t)(256 / TXV)) <= RMAX && (small || blocks(TXV) >= 512 || TXV == 4)) { \
         const int64_t nchunk = cdiv(items, (int64_t)TXV); \
         const dim3 g((unsigned)blocks(TXV)), b(256); \
-        if (cdiv(len, (int64_t)(256 / TXV)) <= RMAX / 4) launch_kernel((softmax_cols_reg<E, TXV, VW, RMAX / 4>), g, b, 0, s, in, out, len, inner, nchunk); \
-        else launch_kernel((softmax_cols_reg<E, TXV, VW, RMAX>), g, b, 0, s, in, out, len, inner, nchunk); \
+        if (cdiv(len, (int64_t)(256 / TXV)) <= RMAX / 4) launch_kernel((softmax_cols_reg<E, TXV, VW, RMAX / 4, PRO>), g, b, 0, s, in, out, len, inner, nchunk, pro); \
+        else launch_kernel((softmax_cols_reg<E, TXV, VW, RMAX, PRO>), g, b, 0, s, in, out, len, inner, nchunk, pro); \
         return; \
     }
     MYFA_REG(64) MYFA_REG(16) MYFA_REG(8) MYFA_REG(4)
@@ -214,40 +223,76 @@ void launch_cols(const E* in, E* out, int64_t outer, int64_t len, int64_t inner,
     if (LAST || (items > TXV / 2 && blocks(TXV) >= 256)) { \
         const int64_t nchunk = cdiv(items, (int64_t)TXV); \
         const dim3 g((unsigned)blocks(TXV)); \
-        if (big) launch_kernel((softmax_cols_stream<E, TXV, VW, BIG>), g, dim3(BIG), 0, s, in, out, len, inner, nchunk); \
-        else launch_kernel((softmax_cols_stream<E, TXV, VW, 256>), g, dim3(256), 0, s, in, out, len, inner, nchunk); \
+        if (big) launch_kernel((softmax_cols_stream<E, TXV, VW, BIG, PRO>), g, dim3(BIG), 0, s, in, out, len, inner, nchunk, pro); \
+        else launch_kernel((softmax_cols_stream<E, TXV, VW, 256, PRO>), g, dim3(256), 0, s, in, out, len, inner, nchunk, pro); \
         return; \
     }
     MYFA_STREAM(64, false) MYFA_STREAM(16, false) MYFA_STREAM(8, items >= 8) MYFA_STREAM(4, true)
 #undef MYFA_STREAM
 }
 
-template <typename E>
-int softmax_cols_any(const E* in, E* out, int64_t outer, int64_t len, int64_t inner, hipStream_t s) {
+template <typename E, bool PRO>
+int softmax_cols_any(const E* in, E* out, int64_t outer, int64_t len, int64_t inner, const Prologue& pro, hipStream_t s) {
     constexpr int VWV = vec_width<E>();
     const bool vec = (inner % VWV == 0) && (reinterpret_cast<uintptr_t>(in) % 16 == 0) &&
                      (reinterpret_cast<uintptr_t>(out) % 16 == 0);
     if (outer * cdiv(inner, (int64_t)(vec ? VWV : 1) * 4) > 0x7fffffffLL)
         return fail(MYFA_E_UNSUPPORTED, "softmax: outer=%lld x inner=%lld exceeds the grid limit", (long long)outer, (long long)inner);
-    if (vec) launch_cols<E, VWV>(in, out, outer, len, inner, s);
-    else launch_cols<E, 1>(in, out, outer, len, inner, s);
+    if (vec) launch_cols<E, VWV, PRO>(in, out, outer, len, inner, pro, s);
+    else launch_cols<E, 1, PRO>(in, out, outer, len, inner, pro, s);
     return check_launch("softmax_cols");
 }
 
 }  // namespace
 
-// dtype: MYFA_F32, MYFA_F16 or MYFA_BF16 (element type of both tensors; arithmetic is float32)
-int softmax_strided(const void* in, void* out, int64_t outer, int64_t len, int64_t inner, int dtype, hipStream_t s) {
+namespace {
+int check_sizes(const void* in, const void* out, int64_t outer, int64_t len, int64_t inner, int dtype, bool& empty) {
+    empty = false;
     if (outer < 0 || len < 0 || inner < 0)
         return fail(MYFA_E_INVALID, "softmax: negative size outer=%lld len=%lld inner=%lld", (long long)outer, (long long)len, (long long)inner);
     if (dtype != MYFA_F32 && dtype != MYFA_F16 && dtype != MYFA_BF16) return fail(MYFA_E_INVALID, "softmax: unknown dtype tag %d", dtype);
-    if (outer == 0 || len == 0 || inner == 0) return MYFA_OK;
+    if (outer == 0 || len == 0 || inner == 0) { empty = true; return MYFA_OK; }
     if (!in || !out) return fail(MYFA_E_INVALID, "softmax: null pointer");
+    return MYFA_OK;
+}
+}  // namespace
+
+// dtype: MYFA_F32, MYFA_F16 or MYFA_BF16 (element type of both tensors; arithmetic is float32)
+int softmax_strided(const void* in, void* out, int64_t outer, int64_t len, int64_t inner, int dtype, hipStream_t s) {
+    bool empty;
+    if (const int rc = check_sizes(in, out, outer, len, inner, dtype, empty); rc != MYFA_OK || empty) return rc;
     if (inner == 1) return softmax_rows(in, out, outer, len, dtype, s);
+    const Prologue none{};
     switch (dtype) {
-        case MYFA_F32:  return softmax_cols_any<float>(static_cast<const float*>(in), static_cast<float*>(out), outer, len, inner, s);
-        case MYFA_F16:  return softmax_cols_any<_Float16>(static_cast<const _Float16*>(in), static_cast<_Float16*>(out), outer, len, inner, s);
-        default:        return softmax_cols_any<__bf16>(static_cast<const __bf16*>(in), static_cast<__bf16*>(out), outer, len, inner, s);
+        case MYFA_F32:  return softmax_cols_any<float, false>(static_cast<const float*>(in), static_cast<float*>(out), outer, len, inner, none, s);
+        case MYFA_F16:  return softmax_cols_any<_Float16, false>(static_cast<const _Float16*>(in), static_cast<_Float16*>(out), outer, len, inner, none, s);
+        default:        return softmax_cols_any<__bf16, false>(static_cast<const __bf16*>(in), static_cast<__bf16*>(out), outer, len, inner, none, s);
+    }
+}
+
+// softmax(scale * x + mask) along `len`, optionally with the causal mask of square logits.
+//   mask: float32 [mask_outer, len, inner] or null; outer index o uses slice o % mask_outer
+//   causal: inner must be 1 and outer a multiple of len: row o is query o % len of a [.., len, len] tensor
+int softmax_strided_pro(const void* in, void* out, int64_t outer, int64_t len, int64_t inner, int dtype,
+                        float scale, const float* mask, int64_t mask_outer, bool causal, hipStream_t s) {
+    bool empty;
+    if (const int rc = check_sizes(in, out, outer, len, inner, dtype, empty); rc != MYFA_OK) return rc;
+    if (mask != nullptr && (mask_outer < 1 || (!empty && outer % mask_outer != 0)))
+        return fail(MYFA_E_INVALID, "softmax: mask_outer=%lld must be >= 1 and divide outer=%lld", (long long)mask_outer, (long long)outer);
+    if (causal && (inner != 1 || (len > 0 && outer % len != 0)))
+        return fail(MYFA_E_UNSUPPORTED, "softmax: the causal flag needs the last dimension of square logits "
+                    "(inner == 1, outer a multiple of len; got outer=%lld len=%lld inner=%lld)", (long long)outer, (long long)len, (long long)inner);
+    if (empty) return MYFA_OK;
+    Prologue pro;
+    pro.scale = scale;
+    pro.mask = mask;
+    pro.mask_outer = mask != nullptr ? mask_outer : 1;
+    pro.causal_rows = causal ? len : 0;
+    if (inner == 1) return softmax_rows_pro(in, out, outer, len, dtype, pro, s);
+    switch (dtype) {
+        case MYFA_F32:  return softmax_cols_any<float, true>(static_cast<const float*>(in), static_cast<float*>(out), outer, len, inner, pro, s);
+        case MYFA_F16:  return softmax_cols_any<_Float16, true>(static_cast<const _Float16*>(in), static_cast<_Float16*>(out), outer, len, inner, pro, s);
+        default:        return softmax_cols_any<__bf16, true>(static_cast<const __bf16*>(in), static_cast<__bf16*>(out), outer, len, inner, pro, s);
     }
 }
 

@@ -108,11 +108,22 @@ def softmax_rows(inp):
     return out
 
 
-def softmax(inp, dim=-1):
-    """torch.softmax(inp, dim) for a contiguous float32, float16 or bfloat16 tensor of any rank;
-    returns a new tensor of the same dtype.  New surface (the reference's my_softmax is rows of
-    a 2-D float32 matrix, csrc/api.cpp:110-166): the tensor is viewed as [outer, len, inner]
-    around `dim`, the last dimension goes to the row kernel, any other to the column kernels."""
+SOFTMAX_CAUSAL = 1   # MYFA_SOFTMAX_CAUSAL
+
+
+def softmax(inp, dim=-1, scale=1.0, mask=None, causal=False):
+    """torch.softmax(scale * inp + mask, dim) for a contiguous float32, float16 or bfloat16 tensor of
+    any rank; returns a new tensor of the same dtype.  New surface (the reference's my_softmax is
+    rows of a 2-D float32 matrix, csrc/api.cpp:110-166): the tensor is viewed as [outer, len, inner]
+    around `dim`, the last dimension goes to the row kernels, any other to the column kernels.
+
+    scale, mask and causal are fused into the load (no extra pass over the logits), for callers that
+    keep the reference's attention as matmul -> softmax -> matmul (csrc/api.cpp:186-187):
+      mask    float32 tensor whose shape equals the trailing dimensions of inp from some dimension
+              <= dim on (e.g. (N, N) for (B, H, N, N) logits); it is broadcast over the leading ones
+      causal  dim must be the last dimension and the last two dimensions equal: element j of row i
+              is hidden when j > i, as scaled_dot_product_attention(is_causal=True) does
+    """
     _check_input(inp, "inp")
     if inp.dtype not in _DTYPE_TAG:
         raise RuntimeError(f"unsupported dtype {inp.dtype}")
@@ -127,9 +138,29 @@ def softmax(inp, dim=-1):
     for n in inp.shape[dim + 1:]:
         inner *= n
     out = torch.empty_like(inp)
+    plain = mask is None and not causal and float(scale) == 1.0
+    mask_outer = 1
+    if mask is not None:
+        _check_input(mask, "mask")
+        _same_device(mask, inp, "mask")
+        _check_float(mask, "mask")
+        k = mask.dim()
+        if k < inp.dim() - dim or k > inp.dim() or tuple(mask.shape) != tuple(inp.shape[inp.dim() - k:]):
+            raise RuntimeError(f"mask shape {tuple(mask.shape)} must equal the trailing dimensions of the input "
+                               f"{tuple(inp.shape)} from some dimension <= dim on")
+        for n in inp.shape[inp.dim() - k:dim]:
+            mask_outer *= n
+    if causal and (dim != inp.dim() - 1 or inp.dim() < 2 or inp.shape[-1] != inp.shape[-2]):
+        raise RuntimeError("causal=True needs dim to be the last dimension of (..., N, N) logits")
     with _on(inp):
-        _lib.check(_lib.lib.myfa_softmax_nd(inp.data_ptr(), out.data_ptr(), outer, inp.shape[dim], inner,
-                                            _DTYPE_TAG[inp.dtype], _stream()))
+        if plain:
+            _lib.check(_lib.lib.myfa_softmax_nd(inp.data_ptr(), out.data_ptr(), outer, inp.shape[dim], inner,
+                                                _DTYPE_TAG[inp.dtype], _stream()))
+        else:
+            _lib.check(_lib.lib.myfa_softmax_nd_ex(inp.data_ptr(), out.data_ptr(), outer, inp.shape[dim], inner,
+                                                   _DTYPE_TAG[inp.dtype], float(scale),
+                                                   mask.data_ptr() if mask is not None else None, mask_outer,
+                                                   SOFTMAX_CAUSAL if causal else 0, _stream()))
     return out
 
 

@@ -24,6 +24,7 @@ EXPORTS = (
     "myfa_softmax_f32",
     "myfa_softmax",
     "myfa_softmax_nd",
+    "myfa_softmax_nd_ex",
     "myfa_attn_fwd_f32",
     "myfa_attn_fwd_bhnd",
     "myfa_attn_fwd_bhnd_ex",
@@ -53,6 +54,8 @@ def _load():
     lib.myfa_softmax.restype = ci
     lib.myfa_softmax_nd.argtypes = [vp, vp, i64, i64, i64, ci, vp]
     lib.myfa_softmax_nd.restype = ci
+    lib.myfa_softmax_nd_ex.argtypes = [vp, vp, i64, i64, i64, ci, f32, vp, i64, ci, vp]
+    lib.myfa_softmax_nd_ex.restype = ci
     lib.myfa_attn_fwd_f32.argtypes = [vp, vp, vp, vp, i64, i64, f32, vp]
     lib.myfa_attn_fwd_f32.restype = ci
     lib.myfa_attn_fwd_bhnd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, ci, vp]

@@ -93,6 +93,26 @@ int myfa_softmax_nd(const void* in, void* out, int64_t outer, int64_t len, int64
                     int dtype, void* stream);
 
 /*
+ * myfa_softmax_nd with a fused prologue: out[o, :, i] = softmax(scale * in[o, :, i] + mask[o % mask_outer, :, i]),
+ * and with MYFA_SOFTMAX_CAUSAL element j of row o hidden (-inf) when j > o % len.
+ *
+ * For callers that keep the reference's composition of attention, matmul -> softmax -> matmul
+ * (csrc/api.cpp:186-187: QK = my_matmul_cublas(Q, K); W = my_softmax(QK)): the logit scale, an
+ * additive mask (padding, ALiBi, ...) and the causal mask cost no extra pass over the N x N logits.
+ *   scale       multiplies every element first (1.0f: none)
+ *   add_mask    float32, dense [mask_outer, len, inner], or NULL; outer must be a multiple of
+ *               mask_outer (mask_outer = 1 broadcasts one [len, inner] mask over everything; for
+ *               [B, H, N, N] logits softmaxed along the last dimension an [N, N] mask is mask_outer = N);
+ *               -inf entries are allowed, a slice that is -inf throughout gives NaN as torch.softmax does
+ *   flags       MYFA_SOFTMAX_CAUSAL needs inner == 1 and outer a multiple of len (the last dimension of
+ *               [..., len, len] logits); otherwise MYFA_E_UNSUPPORTED.  Unknown bits are an error.
+ * scale = 1, add_mask = NULL, flags = 0 computes what myfa_softmax_nd computes.
+ */
+#define MYFA_SOFTMAX_CAUSAL 1
+int myfa_softmax_nd_ex(const void* in, void* out, int64_t outer, int64_t len, int64_t inner, int dtype,
+                       float scale, const float* add_mask, int64_t mask_outer, int flags, void* stream);
+
+/*
  * 2-D single-head attention, float32, the reference's calling convention:
  *     o = softmax(scale * (q @ k_t)) @ v
  * q: [n, d]; k_t: [d, n] (K already transposed, as the reference's caller

@@ -90,10 +90,10 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--only", default=None, help="regenerate one section only (softmax_dim), keeping the rest of the manifest")
     args = ap.parse_args()
-    if args.only == "softmax_dim":
+    if args.only in ("softmax_dim", "softmax_fused"):
         with open(os.path.join(args.out, "MANIFEST.json")) as f:
             manifest = json.load(f)
-        softmax_dim_section(args, manifest)
+        (softmax_dim_section if args.only == "softmax_dim" else softmax_fused_section)(args, manifest)
         with open(os.path.join(args.out, "MANIFEST.json"), "w") as f:
             json.dump(manifest, f, indent=1, sort_keys=True)
         return
@@ -214,6 +214,7 @@ def main():
         print(name, rec)
 
     softmax_dim_section(args, manifest)
+    softmax_fused_section(args, manifest)
 
     with open(os.path.join(args.out, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
@@ -233,6 +234,51 @@ def softmax_dim_section(args, manifest):
         np.savez_compressed(os.path.join(args.out, name + ".npz"), x=x.numpy(), dim=np.int64(dim),
                             out_torch_f64=o_pt.astype(np.float32))
         manifest["softmax_dim"][name] = rec
+        print(name, rec)
+
+
+# (shape, dim, scale, mask shape or None, causal): softmax(scale * x + mask) with the mask
+# broadcast from the right and -inf planted in it; pinned to torch.softmax in float64
+SOFTMAX_FUSED_CASES = [
+    ((2, 3, 40, 40), -1, 0.125, (40, 40), False),
+    ((2, 2, 33, 33), -1, 0.7, None, True),
+    ((3, 50, 50), -1, 1.0, (3, 50, 50), True),
+    ((4, 37, 96), 1, 0.5, (37, 96), False),
+    ((2, 300, 20), 1, 2.0, (2, 300, 20), False),
+    ((5, 64), -1, 0.3, (64,), False),
+]
+
+
+def softmax_fused_section(args, manifest):
+    manifest["softmax_fused"] = {}
+    for n, (shape, dim, scale, mshape, causal) in enumerate(SOFTMAX_FUSED_CASES):
+        torch.manual_seed(10 + n)
+        x = torch.randn(*shape, dtype=torch.float32) * 3
+        mask = None
+        if mshape is not None:
+            mask = torch.randn(*mshape, dtype=torch.float32)
+            mask[torch.rand(*mshape) < 0.2] = float("-inf")
+            # keep one finite entry in every slice along the softmax axis of the mask
+            md = dim if dim < 0 else dim - len(shape)
+            if -md <= len(mshape):
+                idx = [slice(None)] * len(mshape)
+                idx[md] = 0
+                mask[tuple(idx)] = 0.25
+        z = x.double() * scale
+        if mask is not None:
+            z = z + mask.double()
+        if causal:
+            nn = shape[-1]
+            z = z.masked_fill(torch.ones(nn, nn, dtype=torch.bool).triu(1), float("-inf"))
+        o_pt = torch.softmax(z, dim=dim).numpy()
+        o_np = ref_cpu.softmax_dim(x.numpy(), dim, scale=scale, mask=None if mask is None else mask.numpy(), causal=causal)
+        rec = {"oracle_np_vs_torch_f64": maxdiff(o_np, o_pt), "x_sha256": sha(x.numpy())}
+        assert rec["oracle_np_vs_torch_f64"] <= 1e-15, rec
+        name = f"softmax_fused_{n}_" + "x".join(map(str, shape))
+        np.savez_compressed(os.path.join(args.out, name + ".npz"), x=x.numpy(), dim=np.int64(dim), scale=np.float64(scale),
+                            mask=np.zeros(0, np.float32) if mask is None else mask.numpy(), has_mask=np.bool_(mask is not None),
+                            causal=np.bool_(causal), out_torch_f64=o_pt.astype(np.float32))
+        manifest["softmax_fused"][name] = rec
         print(name, rec)
 
 

@@ -47,12 +47,26 @@ def softmax_rows(x, dtype=np.float64):
     return e / e.sum(axis=1, keepdims=True)
 
 
-def softmax_dim(x, axis, dtype=np.float64):
+def softmax_dim(x, axis, dtype=np.float64, scale=1.0, mask=None, causal=False):
     """The same three steps along any one axis of an array of any rank: what
-    torch.softmax(x, dim) computes; axis = -1 of a 2-D array is softmax_rows."""
-    x = _as(x, dtype)
-    e = np.exp(x - x.max(axis=axis, keepdims=True))
-    return e / e.sum(axis=axis, keepdims=True)
+    torch.softmax(x, dim) computes; axis = -1 of a 2-D array is softmax_rows.
+
+    With scale / mask / causal: softmax(scale * x + mask) -- the softmax step of the reference's
+    attention composition (api.cpp:186-187: W = my_softmax(my_matmul_cublas(Q, K))) with the
+    logit scale, an additive mask (numpy-broadcast against x from the right, -inf allowed) and
+    the causal mask of (..., N, N) logits (element j of row i hidden when j > i; axis must be the
+    last one) folded into the first step.  A slice that is -inf throughout is NaN, as in torch."""
+    x = _as(x, dtype) * dtype(scale)
+    if mask is not None:
+        x = x + _as(mask, dtype)
+    if causal:
+        if axis not in (-1, x.ndim - 1) or x.ndim < 2 or x.shape[-1] != x.shape[-2]:
+            raise ValueError("causal needs the last axis of (..., N, N) logits")
+        n = x.shape[-1]
+        x = np.where(np.arange(n)[None, :] > np.arange(n)[:, None], -np.inf, x)
+    with np.errstate(invalid="ignore"):
+        e = np.exp(x - x.max(axis=axis, keepdims=True))
+        return e / e.sum(axis=axis, keepdims=True)
 
 
 def attention_naive(q, k, v, scale=1.0, dtype=np.float64):

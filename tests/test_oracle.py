@@ -155,3 +155,18 @@ def test_softmax_dim_oracle_vs_golden(name):
     moved = np.moveaxis(x, dim, -1)
     rows = ref_cpu.softmax_rows(moved.reshape(-1, moved.shape[-1])).reshape(moved.shape)
     assert np.abs(np.moveaxis(rows, -1, dim) - out).max() <= 1e-15
+
+
+SOFTMAX_FUSED = ["softmax_fused_0_2x3x40x40", "softmax_fused_1_2x2x33x33", "softmax_fused_2_3x50x50",
+                 "softmax_fused_3_4x37x96", "softmax_fused_4_2x300x20", "softmax_fused_5_5x64"]
+
+
+@pytest.mark.parametrize("name", SOFTMAX_FUSED)
+def test_softmax_fused_oracle_vs_golden(name):
+    """softmax(scale * x + mask) with -inf mask entries and the causal mask: the numpy oracle
+    against the stored float64 torch.softmax of the composed input."""
+    g = load_golden(name)
+    mask = g["mask"] if bool(g["has_mask"]) else None
+    out = ref_cpu.softmax_dim(g["x"], int(g["dim"]), scale=float(g["scale"]), mask=mask, causal=bool(g["causal"]))
+    assert np.isfinite(out).all()
+    assert np.abs(out - g["out_torch_f64"]).max() <= 1e-7
