@@ -28,15 +28,21 @@
 //                 A = V[key 4r + g][64bb + 4j + t] (float4 per lane), so accumulator
 //                 4bb + t holds O[query j][64bb + 16g + 4r' + t] in register r' -- sixteen
 //                 consecutive output columns per lane, stored as four float4.
-// The running max is shared by the four lanes (g) of a query through two lane
-// exchanges per tile; the row sum stays a per-lane partial until the end.
+// The running max is shared by the four lanes (g) of a query through two register lane
+// exchanges per tile (v_permlane32_swap, v_permlane16_swap); the row sum stays a per-lane
+// partial until the end.
 //
 // Parallelism.  A workgroup is QG x KS waves: QG groups of 16 queries that walk the
 // same keys together (so K/V tiles are fetched once per workgroup as far as L1 is
 // concerned) times KS interleaved shares of the key tiles, merged through LDS at
 // the end.  The host picks KS > 1 only when there are too few query groups to fill
-// the chip (the reference's single-head shapes), so no workspace is ever needed.
+// the chip (the reference's single-head shapes).
+// With a caller workspace the keys are also split over ZS workgroups (blockIdx.z): each writes
+// its un-normalised partial (O, m, l) and attn_f32_merge_kernel combines them, so that the
+// reference's largest test shape (1024 x 64, one head: 64 query groups) runs on every CU instead
+// of 64 of them with four waves sharing each matrix pipe.
 #include "myfa_common.h"
+#include "tuning.h"
 
 namespace myfa {
 namespace {
@@ -59,7 +65,8 @@ template <int NB, bool KT, bool VEC, bool CAUSAL = false>
 __global__ void __launch_bounds__(max_waves<NB>() * 64)
 attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
                     const float* __restrict__ Vg, float* __restrict__ Og, float* __restrict__ LSEg,
-                    int N, int d, int QG, int KS, long long head_stride, float scale) {
+                    int N, int d, int QG, int KS, long long head_stride, float scale,
+                    int ZS, float* __restrict__ ws_o, float* __restrict__ ws_ml) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NBB = NB / 4;                    // 64-wide column groups
     constexpr bool PREFETCH = NB <= 8;             // K and V of a tile held whole, fetched ahead of use
@@ -79,6 +86,9 @@ attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
     // causal: the wave's 16 rows see the key tiles up to their own (diagonal) tile, whose first
     // key is visible to every one of them
     const int ntiles = CAUSAL ? min((N + 15) >> 4, blockIdx.x * QG + qg + 1) : (N + 15) >> 4;
+    // this workgroup's slice of the key tiles (everything unless the keys are split over blockIdx.z)
+    const int tpz = (ntiles + ZS - 1) / ZS;
+    const int t0 = blockIdx.z * tpz, t1 = min(ntiles, t0 + tpz);
 
     // four consecutive floats of a row (zero past column d)
     auto row4 = [&](const float* row, int col) __attribute__((always_inline)) -> f32x4 {
@@ -124,9 +134,9 @@ attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
 #pragma unroll
         for (int b = 0; b < NB; ++b) kf[b] = k4(key, 16 * b + 4 * g);
     };
-    if constexpr (PREFETCH) load_k(max(min(split, ntiles - 1), 0));
+    if constexpr (PREFETCH) load_k(max(min(t0 + split, ntiles - 1), 0));
 
-    for (int kt = split; kt < ntiles; kt += KS) {
+    for (int kt = t0 + split; kt < t1; kt += KS) {
         const int key0 = kt * 16;
         // ---- V of this tile is requested now and consumed after the logits
         [[maybe_unused]] f32x4 vf[PREFETCH ? 4 : 1][PREFETCH ? NBB : 1];
@@ -179,8 +189,7 @@ attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
             x[r] = c[r] * dscale;
             if (visible(key0 + 4 * r + g)) tmax = fmaxf(tmax, (float)x[r]);
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        tmax = four_rows_allreduce(tmax, MaxOp{});
         const float m_new = fmaxf(m, tmax);
         const float alpha = exp_or_zero(m, m_new);
         if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {    // wave-uniform
@@ -217,8 +226,7 @@ attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
     }
 
     // the four lanes of a query hold partial row sums over their own keys
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
+    l = four_rows_allreduce(l, SumOp{});
 
     // ---- merge the KS key shares of each query group through LDS (share 0 collects)
     constexpr int kSlot = (NB * 4 + 2) * 64;       // floats per parked wave state
@@ -251,8 +259,12 @@ attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
     if (split != 0 || qrow >= N) return;
 
     // ---- store: accumulator 4bb + t, register r holds column 64bb + 16g + 4r + t
-    const float inv = 1.0f / l;
-    float* orow = Og + hoff + qrow * d;
+    // (keys split over workgroups: the un-normalised partial and its (m, l) go to the workspace)
+    const bool partial = ZS > 1;
+    const float inv = partial ? 1.0f : 1.0f / l;
+    const long long prow = ((long long)blockIdx.y * ZS + blockIdx.z) * N + qrow;
+    float* orow = partial ? ws_o + prow * d : Og + hoff + qrow * d;
+    if (partial && g == 0) { ws_ml[2 * prow] = m; ws_ml[2 * prow + 1] = l; }
 #pragma unroll
     for (int bb = 0; bb < NBB; ++bb)
 #pragma unroll
@@ -267,12 +279,44 @@ attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
                     if (col + t < d) orow[col + t] = w[t];
             }
         }
-    if (LSEg != nullptr && g == 0) LSEg[(long long)blockIdx.y * N + qrow] = m + logf(l);
+    if (!partial && LSEg != nullptr && g == 0) LSEg[(long long)blockIdx.y * N + qrow] = m + logf(l);
+}
+
+// O[row][col] = sum_s e^(m_s - M) O_s[row][col] / sum_s e^(m_s - M) l_s over the ZS key slices
+// (M = max_s m_s; a slice without keys has m = -inf, l = 0 and drops out).
+__global__ void __launch_bounds__(256)
+attn_f32_merge_kernel(const float* __restrict__ ws_o, const float* __restrict__ ws_ml, float* __restrict__ Og,
+                      float* __restrict__ LSEg, int N, int d, int ZS) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)N * d) return;
+    const int row = (int)(e / d), col = (int)(e - (long long)row * d);
+    const long long head = blockIdx.y;
+    float M = -INFINITY;
+    for (int s = 0; s < ZS; ++s) M = fmaxf(M, ws_ml[2 * ((head * ZS + s) * N + row)]);
+    float num = 0.f, den = 0.f;
+    for (int s = 0; s < ZS; ++s) {
+        const long long pr = (head * ZS + s) * N + row;
+        const float a = exp_or_zero(ws_ml[2 * pr], M);
+        num += a * ws_o[pr * d + col];
+        den += a * ws_ml[2 * pr + 1];
+    }
+    Og[(head * N + row) * d + col] = num / den;
+    if (LSEg != nullptr && col == 0) LSEg[head * N + row] = M + logf(den);
+}
+
+// Key slices over workgroups for a problem with `wgs` workgroups of its own: only when those
+// leave most of the chip idle and every wave still gets two key tiles; a power of two.
+inline int key_slices(int64_t wgs, int64_t ntiles, int ks_in) {
+    const int target = tuning().attn_f32_wgs > 0 ? tuning().attn_f32_wgs : 256;
+    int zs = 1;
+    while (wgs * zs * 2 <= target && ntiles / ((int64_t)zs * 2 * ks_in) >= 2) zs *= 2;
+    return zs;
 }
 
 template <int NB, bool KT, bool VEC, bool CAUSAL = false>
 int launch(const float* q, const float* k, const float* v, float* o, float* lse,
-           int64_t heads, int64_t N, int64_t d, float scale, hipStream_t s) {
+           int64_t heads, int64_t N, int64_t d, float scale, hipStream_t s,
+           float* ws = nullptr, size_t ws_bytes = 0) {
     auto kern = attn_fwd_f32_kernel<NB, KT, VEC, CAUSAL>;
     constexpr int wmax = max_waves<NB>();
     const int64_t qgroups = cdiv(N, 16);
@@ -285,6 +329,14 @@ int launch(const float* q, const float* k, const float* v, float* o, float* lse,
     // Query groups per workgroup share their K/V fetches; keep at least ~2 workgroups per CU.
     int qgn = wmax / ks;
     while (qgn > 1 && cdiv(qgroups, qgn) * heads < 512) qgn /= 2;
+    // With a workspace: four key shares inside the workgroup (one wave per SIMD) and the rest of
+    // the split over workgroups, as far as key_slices() allows.
+    int zs = 1;
+    if (!CAUSAL && ws != nullptr && qgn == 1 && ks > 4) {
+        zs = key_slices(qgroups * heads, ntiles, 4);
+        if (zs > 1 && (size_t)heads * zs * N * (d + 2) * sizeof(float) <= ws_bytes) ks = 4;
+        else zs = 1;
+    }
     const size_t lds_bytes = ks > 1 ? (size_t)(ks - 1) * qgn * (NB * 4 + 2) * 64 * sizeof(float) : 0;
     if (lds_bytes > 160 * 1024)
         return fail(MYFA_E_UNSUPPORTED, "attention (f32): merge buffer of %zu bytes exceeds LDS", lds_bytes);
@@ -294,24 +346,30 @@ int launch(const float* q, const float* k, const float* v, float* o, float* lse,
         if (e != hipSuccess)
             return fail(MYFA_E_LAUNCH, "attention (f32): cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e));
     }
-    const dim3 grid((unsigned)cdiv(qgroups, qgn), (unsigned)heads);
+    const dim3 grid((unsigned)cdiv(qgroups, qgn), (unsigned)heads, (unsigned)zs);
+    float* ws_o = ws;
+    float* ws_ml = zs > 1 ? ws + (size_t)heads * zs * N * d : nullptr;
     launch_kernel(kern, grid, dim3(qgn * ks * 64), lds_bytes, s, q, k, v, o, lse, (int)N, (int)d,
-                       qgn, ks, (long long)(N * d), scale);
+                       qgn, ks, (long long)(N * d), scale, zs, ws_o, ws_ml);
+    if (zs > 1)
+        launch_kernel(attn_f32_merge_kernel, dim3((unsigned)cdiv(N * d, 256), (unsigned)heads), dim3(256), 0, s,
+                      ws_o, ws_ml, o, lse, (int)N, (int)d, zs);
     return check_launch("attn_fwd_f32");
 }
 
 template <int NB>
 int launch_layout(const float* q, const float* k, const float* v, float* o, float* lse,
-                  int64_t heads, int64_t N, int64_t d, bool kt, bool vec, bool causal, float scale, hipStream_t s) {
+                  int64_t heads, int64_t N, int64_t d, bool kt, bool vec, bool causal, float scale, hipStream_t s,
+                  float* ws, size_t ws_bytes) {
     if (causal) {
         if (kt) return fail(MYFA_E_UNSUPPORTED, "attention (f32): the causal mask needs K as [N, d]");
         return vec ? launch<NB, false, true, true>(q, k, v, o, lse, heads, N, d, scale, s)
                    : launch<NB, false, false, true>(q, k, v, o, lse, heads, N, d, scale, s);
     }
-    if (kt) return vec ? launch<NB, true, true>(q, k, v, o, lse, heads, N, d, scale, s)
-                       : launch<NB, true, false>(q, k, v, o, lse, heads, N, d, scale, s);
-    return vec ? launch<NB, false, true>(q, k, v, o, lse, heads, N, d, scale, s)
-               : launch<NB, false, false>(q, k, v, o, lse, heads, N, d, scale, s);
+    if (kt) return vec ? launch<NB, true, true>(q, k, v, o, lse, heads, N, d, scale, s, ws, ws_bytes)
+                       : launch<NB, true, false>(q, k, v, o, lse, heads, N, d, scale, s, ws, ws_bytes);
+    return vec ? launch<NB, false, true>(q, k, v, o, lse, heads, N, d, scale, s, ws, ws_bytes)
+               : launch<NB, false, false>(q, k, v, o, lse, heads, N, d, scale, s, ws, ws_bytes);
 }
 
 }  // namespace
@@ -319,9 +377,11 @@ int launch_layout(const float* q, const float* k, const float* v, float* o, floa
 // K element (key j, dim c) of a head is at k[j * k_key_stride + c * k_d_stride]:
 //   K_t layout [d, N] (the reference's my_attention): k_key_stride = 1, k_d_stride = N
 //   K   layout [N, d] (batched entry point):          k_key_stride = d, k_d_stride = 1
+// `ws` (may be null): float workspace of ws_bytes for key slices over workgroups, see
+// attn_fwd_f32_ws_bytes().
 int attn_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse,
                  int64_t heads, int64_t N, int64_t d, int64_t k_key_stride, int64_t k_d_stride,
-                 float scale, bool causal, hipStream_t s) {
+                 float scale, bool causal, hipStream_t s, float* ws, size_t ws_bytes) {
     if (d > 512) return fail(MYFA_E_UNSUPPORTED, "attention (f32): head dim %lld > 512", (long long)d);
     if (N * d >= (1LL << 31) || heads > 65535)
         return fail(MYFA_E_UNSUPPORTED, "attention (f32): N*d=%lld per head or heads=%lld beyond the kernel's limits", (long long)(N * d), (long long)heads);
@@ -333,10 +393,19 @@ int attn_fwd_f32(const float* q, const float* k, const float* v, float* o, float
     const bool vec = d % 4 == 0 &&
         ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
           reinterpret_cast<uintptr_t>(o)) % 16 == 0);
-    if (d <= 64)  return launch_layout<4>(q, k, v, o, lse, heads, N, d, kt, vec, causal, scale, s);
-    if (d <= 128) return launch_layout<8>(q, k, v, o, lse, heads, N, d, kt, vec, causal, scale, s);
-    if (d <= 256) return launch_layout<16>(q, k, v, o, lse, heads, N, d, kt, vec, causal, scale, s);
-    return launch_layout<32>(q, k, v, o, lse, heads, N, d, kt, vec, causal, scale, s);
+    if (d <= 64)  return launch_layout<4>(q, k, v, o, lse, heads, N, d, kt, vec, causal, scale, s, ws, ws_bytes);
+    if (d <= 128) return launch_layout<8>(q, k, v, o, lse, heads, N, d, kt, vec, causal, scale, s, ws, ws_bytes);
+    if (d <= 256) return launch_layout<16>(q, k, v, o, lse, heads, N, d, kt, vec, causal, scale, s, ws, ws_bytes);
+    return launch_layout<32>(q, k, v, o, lse, heads, N, d, kt, vec, causal, scale, s, ws, ws_bytes);
+}
+
+// Bytes of workspace with which attn_fwd_f32 can spread `heads` problems of N keys over the
+// whole chip; 0 when it would not split the keys over workgroups anyway.
+size_t attn_fwd_f32_ws_bytes(int64_t heads, int64_t N, int64_t d) {
+    if (N <= 0 || d <= 0 || d > 512 || heads <= 0) return 0;
+    const int64_t qgroups = cdiv(N, 16);
+    const int zs = key_slices(qgroups * heads, qgroups, 4);
+    return zs > 1 ? (size_t)heads * zs * N * (d + 2) * sizeof(float) : 0;
 }
 
 }  // namespace myfa

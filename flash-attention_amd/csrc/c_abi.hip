@@ -49,7 +49,8 @@ int softmax_strided_pro(const void* in, void* out, int64_t outer, int64_t len, i
 int matmul_f32(const float* a, const float* b, float* c, int64_t m, int64_t k, int64_t n, hipStream_t s);
 int attn_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse,
                  int64_t heads, int64_t N, int64_t d, int64_t k_key_stride, int64_t k_d_stride,
-                 float scale, bool causal, hipStream_t s);
+                 float scale, bool causal, hipStream_t s, float* ws, size_t ws_bytes);
+size_t attn_fwd_f32_ws_bytes(int64_t heads, int64_t N, int64_t d);
 int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* lse,
                   int64_t heads, int64_t N, int64_t d, float scale, int dtype, bool causal, hipStream_t s);
 int attn_bwd_mfma(const void* q, const void* k, const void* v, const void* o, const float* lse, const void* dout,
@@ -108,7 +109,20 @@ int myfa_attn_fwd_f32(const float* q, const float* k_t, const float* v, float* o
     if (n == 0 || d == 0) return MYFA_OK;
     if (!q || !k_t || !v || !o) return fail(MYFA_E_INVALID, "attention: null pointer");
     // K_t is [d, n]: key stride 1, dim stride n
-    return attn_fwd_f32(q, k_t, v, o, nullptr, 1, n, d, 1, n, scale, false, static_cast<hipStream_t>(stream));
+    return attn_fwd_f32(q, k_t, v, o, nullptr, 1, n, d, 1, n, scale, false, static_cast<hipStream_t>(stream), nullptr, 0);
+}
+
+int64_t myfa_attn_fwd_f32_ws_bytes(int64_t n, int64_t d) { return (int64_t)attn_fwd_f32_ws_bytes(1, n, d); }
+
+int myfa_attn_fwd_f32_ws(const float* q, const float* k_t, const float* v, float* o,
+                         int64_t n, int64_t d, float scale, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (n < 0 || d < 0) return fail(MYFA_E_INVALID, "attention: negative size n=%lld d=%lld", (long long)n, (long long)d);
+    if (n == 0 || d == 0) return MYFA_OK;
+    if (!q || !k_t || !v || !o) return fail(MYFA_E_INVALID, "attention: null pointer");
+    if (workspace_bytes < 0 || (workspace == nullptr && workspace_bytes > 0) || reinterpret_cast<uintptr_t>(workspace) % 16 != 0)
+        return fail(MYFA_E_INVALID, "attention: workspace must be 16-byte aligned with a non-negative size");
+    return attn_fwd_f32(q, k_t, v, o, nullptr, 1, n, d, 1, n, scale, false, static_cast<hipStream_t>(stream),
+                        static_cast<float*>(workspace), (size_t)workspace_bytes);
 }
 
 int myfa_attn_fwd_bhnd(const void* q, const void* k, const void* v, void* o, float* lse,
@@ -132,7 +146,7 @@ int myfa_attn_fwd_bhnd_ex(const void* q, const void* k, const void* v, void* o, 
             // K is [N, d]: key stride d, dim stride 1
             return attn_fwd_f32(static_cast<const float*>(q), static_cast<const float*>(k),
                                 static_cast<const float*>(v), static_cast<float*>(o), lse,
-                                heads, N, d, d, 1, scale, causal, s);
+                                heads, N, d, d, 1, scale, causal, s, nullptr, 0);
         case MYFA_F16:
         case MYFA_BF16:
             if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) |
@@ -201,6 +215,7 @@ int myfa_tuning_set(const char* key, double value) {
     else if (k == "attn_variant") t.attn_variant = (int)value;
     else if (k == "attn_thr") t.attn_thr = (float)value;
     else if (k == "attn_bq") t.attn_bq = (int)value;
+    else if (k == "attn_f32_wgs") t.attn_f32_wgs = (int)value;
     else if (k == "matmul_block") t.matmul_block = (int)value;
     else if (k == "softmax_tpr") t.softmax_shape[0] = (int)value;
     else if (k == "softmax_v") t.softmax_shape[1] = (int)value;

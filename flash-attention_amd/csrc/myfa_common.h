@@ -72,6 +72,22 @@ __device__ __forceinline__ float wave_reduce(float x, Op op) {
     return op(read_lane(x, 0), read_lane(x, 32));
 }
 
+// All-reduce over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (one lane of each 16-lane row), in
+// registers: v_permlane32_swap(x, x) leaves {x.lo | x.lo} and {x.hi | x.hi}, whose combination
+// every lane holds reduced over the two halves; v_permlane16_swap(c, c) leaves {r0 r0 r2 r2} and
+// {r1 r1 r3 r3} (16-lane rows of c), whose combination is the total everywhere.
+template <typename Op>
+__device__ __forceinline__ float four_rows_allreduce(float x, Op op) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned a1 = r1[0], b1 = r1[1];     // (copied out first: see attn_mfma_common.h)
+    const float c = op(__builtin_bit_cast(float, a1), __builtin_bit_cast(float, b1));
+    const unsigned cu = __builtin_bit_cast(unsigned, c);
+    const auto r2 = __builtin_amdgcn_permlane16_swap(cu, cu, false, false);
+    const unsigned a2 = r2[0], b2 = r2[1];
+    return op(__builtin_bit_cast(float, a2), __builtin_bit_cast(float, b2));
+}
+
 __device__ __forceinline__ float wave_max(float x) { return wave_reduce(x, MaxOp{}); }
 __device__ __forceinline__ float wave_sum(float x) { return wave_reduce(x, SumOp{}); }
 

@@ -24,6 +24,8 @@ struct Tuning {
     int attn_bq = 0;
     // device buffer for the stamped (cycle-counting) diagnostic build, 24 u64 per workgroup
     unsigned long long* attn_dbg = nullptr;
+    // float32 attention, keys split over workgroups: workgroup count the split aims at (0 = the default, 256)
+    int attn_f32_wgs = 0;
     // row softmax launch shape override: threads per row, items per thread, map, nt, pad (tpr = 0: none)
     int softmax_shape[5] = {0, 0, 0, 3, 0};
     // float32 matmul block edge: 0 = library's choice, 64 or 128

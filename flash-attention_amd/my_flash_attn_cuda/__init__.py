@@ -178,10 +178,19 @@ def my_attention(Q, K, V):
     n, d = Q.shape
     if not (K.shape[0] == d and K.shape[1] == n and V.shape[0] == n and V.shape[1] == d):
         raise RuntimeError("Wrong sizes!")
+    _same_device(K, Q, "K"); _same_device(V, Q, "V")
     out = torch.empty_like(Q)
     with _on(Q):
-        _lib.check(_lib.lib.myfa_attn_fwd_f32(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(),
-                                              n, d, 1.0, _stream()))
+        # one head has too few query groups for the chip: with a workspace (torch's caching
+        # allocator, stream-ordered) the library also splits the keys over workgroups
+        nbytes = _lib.lib.myfa_attn_fwd_f32_ws_bytes(n, d)
+        if nbytes > 0:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=Q.device)
+            _lib.check(_lib.lib.myfa_attn_fwd_f32_ws(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(),
+                                                     n, d, 1.0, ws.data_ptr(), nbytes, _stream()))
+        else:
+            _lib.check(_lib.lib.myfa_attn_fwd_f32(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(),
+                                                  n, d, 1.0, _stream()))
     return out
 
 
@@ -202,6 +211,7 @@ def flash_attn_fwd(q, k, v, scale=1.0, return_lse=False, causal=False):
     scaled_dot_product_attention(is_causal=True) does (the reference has no mask).
     """
     _check_input(q, "q"); _check_input(k, "k"); _check_input(v, "v")
+    _same_device(k, q, "k"); _same_device(v, q, "v")
     if q.dim() != 4:
         raise RuntimeError(f"flash_attn_fwd expects (B, H, N, d) tensors, got {q.dim()}-D")
     if not (q.shape == k.shape == v.shape):
@@ -228,6 +238,7 @@ def flash_attn_bwd(dout, q, k, v, out, lse, scale=1.0, causal=False):
     it sketches (csrc/my_flash_attn/flash_attention.cu:23-69)."""
     for t, name in ((dout, "dout"), (q, "q"), (k, "k"), (v, "v"), (out, "out"), (lse, "lse")):
         _check_input(t, name)
+        _same_device(t, q, name)
     if q.dim() != 4 or not (q.shape == k.shape == v.shape == out.shape == dout.shape):
         raise RuntimeError("Wrong sizes!")
     if not (q.dtype == k.dtype == v.dtype == out.dtype == dout.dtype):
@@ -303,6 +314,7 @@ def flash_attn_func(q, k, v, scale=1.0, causal=False):
 
 def _matmul_checks(A, B):
     _check_input(A, "A"); _check_input(B, "B")
+    _same_device(B, A, "B")
     if A.dim() != 2 or B.dim() != 2 or A.shape[1] != B.shape[0]:
         raise RuntimeError("Size mismatch!")
 
@@ -323,12 +335,14 @@ def my_matmul(A, B):
 
 def my_matmul_cublas(A, B):
     _matmul_checks(A, B)
+    _check_float(A, "A"); _check_float(B, "B")   # the reference reads data_ptr<float>() (api.cpp:96-99)
     return torch.matmul(A, B)
 
 
 def my_matmul_out(out, A, B):
     _check_input(out, "out")
     _matmul_checks(A, B)
+    _same_device(out, A, "out")
     if tuple(out.shape) != (A.shape[0], B.shape[1]):
         raise RuntimeError("Size mismatch!")
     if not (out.dtype == A.dtype == B.dtype):

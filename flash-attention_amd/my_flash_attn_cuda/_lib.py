@@ -26,6 +26,8 @@ EXPORTS = (
     "myfa_softmax_nd",
     "myfa_softmax_nd_ex",
     "myfa_attn_fwd_f32",
+    "myfa_attn_fwd_f32_ws_bytes",
+    "myfa_attn_fwd_f32_ws",
     "myfa_attn_fwd_bhnd",
     "myfa_attn_fwd_bhnd_ex",
     "myfa_attn_bwd_bhnd",
@@ -58,6 +60,10 @@ def _load():
     lib.myfa_softmax_nd_ex.restype = ci
     lib.myfa_attn_fwd_f32.argtypes = [vp, vp, vp, vp, i64, i64, f32, vp]
     lib.myfa_attn_fwd_f32.restype = ci
+    lib.myfa_attn_fwd_f32_ws_bytes.argtypes = [i64, i64]
+    lib.myfa_attn_fwd_f32_ws_bytes.restype = i64
+    lib.myfa_attn_fwd_f32_ws.argtypes = [vp, vp, vp, vp, i64, i64, f32, vp, i64, vp]
+    lib.myfa_attn_fwd_f32_ws.restype = ci
     lib.myfa_attn_fwd_bhnd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, ci, vp]
     lib.myfa_attn_fwd_bhnd.restype = ci
     lib.myfa_attn_fwd_bhnd_ex.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, ci, ci, vp]

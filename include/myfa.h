@@ -127,6 +127,21 @@ int myfa_attn_fwd_f32(const float* q, const float* k_t, const float* v, float* o
                       int64_t n, int64_t d, float scale, void* stream);
 
 /*
+ * myfa_attn_fwd_f32 with a caller workspace, for the single-head shapes of the reference's tests
+ * (tests/test_flash_attn.py:155: N up to 1025): one head has N/16 query groups, far fewer than the
+ * chip has matrix pipes, so with a workspace the keys are also split over workgroups and the
+ * partial results merged by a second small kernel.  myfa_attn_fwd_f32_ws_bytes(n, d) is the size
+ * that lets the library do so (0: it would not split; any smaller workspace, or NULL, falls back
+ * to what myfa_attn_fwd_f32 does).  The workspace is scratch: its contents before and after the
+ * call mean nothing; it must stay untouched until the call's work on `stream` has finished.
+ * Same result as myfa_attn_fwd_f32 up to float32 rounding of the merge.
+ */
+int64_t myfa_attn_fwd_f32_ws_bytes(int64_t n, int64_t d);
+int myfa_attn_fwd_f32_ws(const float* q, const float* k_t, const float* v, float* o,
+                         int64_t n, int64_t d, float scale,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
  * Batched multi-head attention forward, no mask, no dropout:
  *     o[b,h] = softmax(scale * q[b,h] @ k[b,h]^T) @ v[b,h]
  * q, k, v, o: dense [B, H, N, d] of `dtype` (MYFA_F32 / MYFA_F16 / MYFA_BF16);
@@ -139,8 +154,10 @@ int myfa_attn_fwd_f32(const float* q, const float* k_t, const float* v, float* o
  * (out, Q, K, V, seq_len, d_head), host wrapper allocating out, l, m); its
  * math is the reference's Python Algorithm-1 restatement
  * (tests/test_flash_attn.py:46-101) applied per (batch, head).
- * MYFA_F16 / MYFA_BF16 run on MFMA and require d in {64, 128}; MYFA_F32 accepts
- * any d >= 1.
+ * MYFA_F16 / MYFA_BF16 run on MFMA and require d in {64, 128} and scale > 0; MYFA_F32 accepts
+ * 1 <= d <= 512, B*H <= 65535 and N*d < 2^31 (myfa_attn_fwd_f32 has the same d and N*d limits;
+ * the reference's my_attention has none, but its test shapes end at N = 1025, d = 99).  Outside
+ * these limits the call returns MYFA_E_UNSUPPORTED.
  */
 int myfa_attn_fwd_bhnd(const void* q, const void* k, const void* v, void* o, float* lse,
                        int64_t B, int64_t H, int64_t N, int64_t d,

@@ -63,6 +63,33 @@ def test_my_attention_more_shapes(mfa, n, d):
     assert _maxdiff(out.cpu().numpy(), ref_cpu.attention_naive(q.numpy(), k.numpy(), v.numpy())) <= F32_ATOL
 
 
+@pytest.mark.parametrize("n,d", [(1024, 64), (1023, 63), (1025, 65), (2048, 128), (2000, 20), (700, 300)])
+def test_my_attention_key_slices_with_and_without_workspace(mfa, n, d):
+    """Through the C ABI: with a workspace of the advertised size the keys are split over
+    workgroups and merged by the second kernel; with none (or too small a one) the call does what
+    myfa_attn_fwd_f32 does.  All must meet the float64 oracle to 1e-5, the reference's own
+    shapes included (tests/test_flash_attn.py:155)."""
+    from my_flash_attn_cuda import _lib
+    lib = _lib.lib
+    torch.manual_seed(1)
+    q, k, v = (torch.randn(n, d, dtype=torch.float32) for _ in range(3))
+    exact = ref_cpu.attention_naive(q.numpy(), k.numpy(), v.numpy())
+    qd, ktd, vd = q.cuda(), k.t().contiguous().cuda(), v.cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    nbytes = lib.myfa_attn_fwd_f32_ws_bytes(n, d)
+    assert nbytes > 0                                   # these shapes are meant to split
+    ws = torch.full((nbytes // 4,), float("nan"), device="cuda")       # scratch may hold anything
+    outs = []
+    for wptr, wlen in ((ws.data_ptr(), nbytes), (None, 0), (ws.data_ptr(), 64)):
+        out = torch.full((n, d), float("nan"), device="cuda")
+        _lib.check(lib.myfa_attn_fwd_f32_ws(qd.data_ptr(), ktd.data_ptr(), vd.data_ptr(), out.data_ptr(),
+                                            n, d, 1.0, wptr, wlen, st))
+        outs.append(out.cpu().numpy())
+        assert _maxdiff(outs[-1], exact) <= F32_ATOL
+    assert np.array_equal(outs[1], outs[2])             # both fell back to the one-kernel path
+    assert lib.myfa_attn_fwd_f32_ws_bytes(16, 64) == 0  # nothing to split
+
+
 def test_my_attention_errors(mfa):
     q = torch.randn(8, 4, device="cuda")
     with pytest.raises(RuntimeError, match="Wrong sizes"):

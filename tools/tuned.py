@@ -29,6 +29,9 @@ class Tuned:
         lib.myfa_attn_fwd_bhnd_ex.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, ci, ci, vp]
         lib.myfa_matmul_f32.argtypes = [vp, vp, vp, i64, i64, i64, vp]
         lib.myfa_softmax_f32.argtypes = [vp, vp, i64, i64, vp]
+        lib.myfa_attn_fwd_f32_ws_bytes.argtypes = [i64, i64]
+        lib.myfa_attn_fwd_f32_ws_bytes.restype = i64
+        lib.myfa_attn_fwd_f32_ws.argtypes = [vp, vp, vp, vp, i64, i64, f32, vp, i64, vp]
 
     def _check(self, rc):
         if rc != 0:
@@ -51,6 +54,15 @@ class Tuned:
             q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr() if return_lse else None,
             B, H, N, d, float(scale), _TAG[q.dtype], 1 if causal else 0, torch.cuda.current_stream().cuda_stream))
         return (out, lse) if return_lse else out
+
+    def my_attention(self, q, kt, v, workspace=True):
+        n, d = q.shape
+        out = torch.empty_like(q)
+        nbytes = self.lib.myfa_attn_fwd_f32_ws_bytes(n, d) if workspace else 0
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=q.device)
+        self._check(self.lib.myfa_attn_fwd_f32_ws(q.data_ptr(), kt.data_ptr(), v.data_ptr(), out.data_ptr(), n, d, 1.0,
+                                                  ws.data_ptr() if nbytes else None, nbytes, torch.cuda.current_stream().cuda_stream))
+        return out
 
     def my_matmul(self, a, b):
         out = torch.empty((a.shape[0], b.shape[1]), dtype=a.dtype, device=a.device)
