@@ -50,6 +50,9 @@ constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
 constexpr int kBQ = kWaves * 32;   // query rows per workgroup
 constexpr int kBKV = 64;           // keys per tile
+// A buffer offset no tensor reaches (the launcher keeps a head below it) and that a tile offset
+// added to it cannot wrap: fetches from there read zero without touching memory.
+constexpr int kPastEndV1 = 0x7FFF0000;
 
 template <typename T, int D>
 __global__ void __launch_bounds__(kThreads, 2)
@@ -290,7 +293,7 @@ template <typename T, int D, bool STAMP = false, bool CAUSAL = false>
 __global__ void __launch_bounds__(kThreads, D == 64 ? 4 : 2)
 attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* __restrict__ Vg,
                         T* __restrict__ Og, float* __restrict__ LSEg, int N, int nqblk, int nwg,
-                        float sl2, float thr, unsigned long long* __restrict__ dbg = nullptr) {
+                        float sl2, float thr, int gd, unsigned long long* __restrict__ dbg = nullptr) {
     using M = Mma<T>;
     using vec8 = typename M::vec8;
     using vec4 = typename M::vec4;
@@ -323,7 +326,10 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
     const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);   // 0: leads, 1: one phase behind
     const int r = lane & 31, h = lane >> 5;
 
-    const size_t hoff = (size_t)head * (size_t)N * D;
+    // gd <= D is the head dim in memory (a multiple of 8): rows are gd elements apart, and the
+    // columns gd .. D-1 of the LDS images are zeros (their chunks are fetched from past the end of
+    // the tensor, where the buffer bounds check answers zero).
+    const size_t hoff = (size_t)head * (size_t)N * gd;
 
     const int qrow = q0 + wave * 32 + r;
     vec8 qf[KS];
@@ -333,7 +339,8 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
     // image is produced by choosing each lane's SOURCE chunk: piece `pc` of a tile covers
     // image bytes [1024 pc, 1024 pc + 1024); lane L owns 16-byte unit u = 64 pc + L, which by
     // the image formula is (row, chunk) below.  Rows past N read as zero (buffer bounds).
-    const unsigned head_bytes = (unsigned)N * D * 2;
+    const unsigned head_bytes = (unsigned)N * gd * 2;
+    const int tile_gb = kBKV * gd * 2;            // bytes of one 64-row tile in memory
     const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)(Kg + hoff), 0, head_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(Vg + hoff), 0, head_bytes, 0x00020000);
     [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -344,7 +351,7 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
         const int grp8 = u / (SUB_B / 16), within = u % (SUB_B / 16);
         const int row = 8 * grp8 + ((within & 31) >> 2);
         const int ch = 4 * (within >> 5) + ((within & 3) ^ ((row >> 2) & 3));
-        st_goff[i] = (row * D + ch * 8) * 2;
+        st_goff[i] = ch * 8 < gd ? (row * gd + ch * 8) * 2 : kPastEndV1;
     }
     // (The host pass of hipcc silently drops a kernel whose body names this builtin, and the
     // launch stub with it; the body only exists in the device pass.)
@@ -358,7 +365,7 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
 #if defined(__HIP_DEVICE_COMPILE__)
         const int te = CAUSAL ? (tile < t_stop ? tile : t_past) : tile;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + lds_byte + 1024 * (wave_u * LPT + i)),
-                                                 16, st_goff[i], te * TILE_B, 0, 0);
+                                                 16, st_goff[i], te * tile_gb, 0, 0);
 #endif
     };
     auto fetch_k = [&](int tile, int slot) __attribute__((always_inline)) {
@@ -526,7 +533,7 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
     const int qbyte = (wave_u < 2 ? 2 : wave_u < 4 ? 3 : wave_u < 6 ? 5 : 6) * TILE_B + (wave_u & 1) * (TILE_B / 2);
     {
         [[maybe_unused]] const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc((void*)(Qg + hoff), 0, head_bytes, 0x00020000);
-        [[maybe_unused]] const int qrow0_b = (q0 + 32 * wave) * D * 2;   // in the lane offset: it is bounds-checked
+        [[maybe_unused]] const int qrow0_b = (q0 + 32 * wave) * gd * 2;   // in the lane offset: it is bounds-checked
 #pragma unroll
         for (int pc = 0; pc < TILE_B / 2 / 1024; ++pc) {
             const int u = 64 * pc + lane;
@@ -535,7 +542,7 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
             [[maybe_unused]] const int ch = 4 * (within >> 5) + ((within & 3) ^ ((row >> 2) & 3));
 #if defined(__HIP_DEVICE_COMPILE__)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (lds_void*)(lds + qbyte + 1024 * pc), 16,
-                                                     qrow0_b + (row * D + ch * 8) * 2, 0, 0, 0);
+                                                     ch * 8 < gd ? qrow0_b + (row * gd + ch * 8) * 2 : kPastEndV1, 0, 0, 0);
 #endif
         }
     }
@@ -646,8 +653,8 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
         for (int k2 = 0; k2 < 32 / RPI; ++k2) {
             const int row = k2 * RPI + lane / CPR, ch = lane % CPR;
             const u32x4 val = *reinterpret_cast<const u32x4*>(obuf + row * OROW_B + ch * 16);
-            if (orow0 + row < N)
-                *reinterpret_cast<u32x4*>(Og + hoff + (size_t)(orow0 + row) * D + ch * 8) = val;
+            if (orow0 + row < N && ch * 8 < gd)
+                *reinterpret_cast<u32x4*>(Og + hoff + (size_t)(orow0 + row) * gd + ch * 8) = val;
         }
         if (LSEg != nullptr && h == 0 && qrow < N)
             LSEg[(size_t)head * N + qrow] = (m + __builtin_amdgcn_logf(ltot)) * 0.6931471805599453f;
@@ -664,13 +671,14 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
 
 template <typename T, int D>
 int launch(const void* q, const void* k, const void* v, void* o, float* lse,
-           int64_t heads, int64_t N, float scale, bool causal, hipStream_t s) {
+           int64_t heads, int64_t N, int64_t d, float scale, bool causal, hipStream_t s) {
+    if (N * d * 2 >= (int64_t)kPastEndV1) return fail(MYFA_E_UNSUPPORTED, "attention: N*d=%lld per head too large", (long long)(N * d));
     const int64_t nqblk = cdiv(N, kBQ);
     const int64_t nwg = heads * nqblk;
     if (nwg > 0x7fffffffLL) return fail(MYFA_E_UNSUPPORTED, "attention: too many workgroups (%lld)", (long long)nwg);
     const float sl2 = scale * 1.4426950408889634f;
     const Tuning& tn = tuning();
-    if (tn.attn_variant == 0 && !causal)
+    if (tn.attn_variant == 0 && !causal && d == D)
         launch_kernel((attn_fwd_mfma_kernel<T, D>), dim3((unsigned)nwg), dim3(kThreads), 0, s,
                            static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
                            static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2);
@@ -678,7 +686,7 @@ int launch(const void* q, const void* k, const void* v, void* o, float* lse,
         auto go = [&](auto kern) {
             launch_kernel(kern, dim3((unsigned)nwg), dim3(kThreads), 0, s,
                                static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
-                               static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, tn.attn_thr, tn.attn_dbg);
+                               static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, tn.attn_thr, (int)d, tn.attn_dbg);
         };
 #ifdef MYFA_TUNING
         if (causal && tn.attn_dbg != nullptr) go(attn_fwd_mfma_pp_kernel<T, D, true, true>);
@@ -708,11 +716,15 @@ int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* l
     const int variant = tuning().attn_variant;
     if (variant == 2 || (variant < 0 && !causal))
         return attn_fwd_mfma16(q, k, v, o, lse, heads, N, d, scale, tuning().attn_thr, dtype, causal, s);
-    if (dtype == MYFA_BF16 && d == 128) return launch<__bf16, 128>(q, k, v, o, lse, heads, N, scale, causal, s);
-    if (dtype == MYFA_BF16 && d == 64)  return launch<__bf16, 64>(q, k, v, o, lse, heads, N, scale, causal, s);
-    if (dtype == MYFA_F16 && d == 128)  return launch<_Float16, 128>(q, k, v, o, lse, heads, N, scale, causal, s);
-    if (dtype == MYFA_F16 && d == 64)   return launch<_Float16, 64>(q, k, v, o, lse, heads, N, scale, causal, s);
-    return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16): head dim %lld not in {64, 128}", (long long)d);
+    // head dims that are multiples of 8 run on the next build up, the missing columns read as zeros
+    if (d >= 8 && d <= 128 && d % 8 == 0) {
+        const bool big = d > 64;
+        if (dtype == MYFA_BF16) return big ? launch<__bf16, 128>(q, k, v, o, lse, heads, N, d, scale, causal, s)
+                                           : launch<__bf16, 64>(q, k, v, o, lse, heads, N, d, scale, causal, s);
+        if (dtype == MYFA_F16)  return big ? launch<_Float16, 128>(q, k, v, o, lse, heads, N, d, scale, causal, s)
+                                           : launch<_Float16, 64>(q, k, v, o, lse, heads, N, d, scale, causal, s);
+    }
+    return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16): head dim %lld is not a multiple of 8 in 8..128", (long long)d);
 }
 
 }  // namespace myfa

@@ -80,12 +80,15 @@ constexpr int kWaves16 = 8;
 constexpr int kThreads16 = kWaves16 * 64;
 constexpr int kBQ16 = kWaves16 * 32;   // query rows per workgroup
 constexpr int kBKV16 = 64;             // keys per tile
+// A buffer offset no tensor reaches (the launcher keeps a head below it) and that a tile offset
+// added to it cannot wrap: fetches from there read zero without touching memory.
+constexpr int kPastEnd = 0x7FFF0000;
 
 template <typename T, int D, bool CAUSAL = false>
 __global__ void __launch_bounds__(kThreads16, D == 64 ? 4 : 2)
 attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* __restrict__ Vg,
                        T* __restrict__ Og, float* __restrict__ LSEg, int N, int nqblk, int nwg,
-                       float sl2, float thr) {
+                       float sl2, float thr, int gd) {
     using M = Mma16<T>;
     using vec8 = typename M::vec8;
     using vec4 = typename M::vec4;
@@ -117,14 +120,19 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
     const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);   // 0: leads, 1: one phase behind
     const int i16 = lane & 15, g = lane >> 4;
 
-    const size_t hoff = (size_t)head * (size_t)N * D;
+    // gd <= D is the head dim in memory (a multiple of 8): rows are gd elements apart, and the
+    // columns gd .. D-1 of the LDS images are zeros (their chunks are fetched from past the end of
+    // the tensor, where the buffer bounds check answers zero), so Q K^T is unchanged and the
+    // padded columns of O are never stored.
+    const size_t hoff = (size_t)head * (size_t)N * gd;
     const int qrow0 = q0 + wave * 32 + i16;      // this lane's query of block 0; block 1: + 16
 
     // ---- K/V tiles go HBM/L2 -> LDS directly (buffer_load ... lds).  One wave-instruction fills
     // 1 KiB of LDS, lane L at base + 16 L, so the image is produced by choosing each lane's SOURCE
     // chunk: lane L of piece pc owns 16-byte unit u = 64 pc + L, which by the image formula is
     // (row, chunk) below.  Rows past N read as zero (buffer bounds check).
-    const unsigned head_bytes = (unsigned)N * D * 2;
+    const unsigned head_bytes = (unsigned)N * gd * 2;
+    const int tile_gb = kBKV16 * gd * 2;          // bytes of one 64-row tile in memory
     const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)(Kg + hoff), 0, head_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(Vg + hoff), 0, head_bytes, 0x00020000);
     [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -132,7 +140,7 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
         const int grp8 = u / (SUB_B / 16), within = u % (SUB_B / 16);
         const int row = 8 * grp8 + ((within & 31) >> 2);
         const int ch = 4 * (within >> 5) + ((within & 3) ^ (2 * ((row >> 2) & 1)));
-        return (row * D + ch * 8) * 2;
+        return ch * 8 < gd ? (row * gd + ch * 8) * 2 : kPastEnd;
     };
     int st_goff[LPT];
 #pragma unroll
@@ -146,7 +154,7 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
 #if defined(__HIP_DEVICE_COMPILE__)
         const int te = CAUSAL ? (tile < t_stop ? tile : t_past) : tile;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds + lds_byte + 1024 * (wave_u * LPT + i)),
-                                                 16, st_goff[i], te * TILE_B, 0, 0);
+                                                 16, st_goff[i], te * tile_gb, 0, 0);
 #endif
     };
     auto fetch_k = [&](int tile, int slot) __attribute__((always_inline)) {
@@ -336,12 +344,13 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
     const int qbyte = (wave_u < 2 ? 2 : wave_u < 4 ? 3 : wave_u < 6 ? 5 : 6) * TILE_B + (wave_u & 1) * (TILE_B / 2);
     {
         [[maybe_unused]] const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc((void*)(Qg + hoff), 0, head_bytes, 0x00020000);
-        [[maybe_unused]] const int qrow0_b = (q0 + 32 * wave) * D * 2;   // in the lane offset: it is bounds-checked
+        [[maybe_unused]] const int qrow0_b = (q0 + 32 * wave) * gd * 2;   // in the lane offset: it is bounds-checked
 #pragma unroll
         for (int pc = 0; pc < TILE_B / 2 / 1024; ++pc) {
             [[maybe_unused]] const int src = unit_src(64 * pc + lane);
 #if defined(__HIP_DEVICE_COMPILE__)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (lds_void*)(lds + qbyte + 1024 * pc), 16, qrow0_b + src, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (lds_void*)(lds + qbyte + 1024 * pc), 16,
+                                                     src == kPastEnd ? kPastEnd : qrow0_b + src, 0, 0, 0);
 #endif
         }
     }
@@ -429,8 +438,8 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
         for (int k2 = 0; k2 < 32 / RPI; ++k2) {
             const int row = k2 * RPI + lane / CPR, ch = lane % CPR;
             const u32x4 val = *reinterpret_cast<const u32x4*>(obuf + row * OROW_B + ch * 16);
-            if (orow0 + row < N)
-                *reinterpret_cast<u32x4*>(Og + hoff + (size_t)(orow0 + row) * D + ch * 8) = val;
+            if (orow0 + row < N && ch * 8 < gd)
+                *reinterpret_cast<u32x4*>(Og + hoff + (size_t)(orow0 + row) * gd + ch * 8) = val;
         }
         // lanes 0-15 hold block 0's statistics for their query, lanes 16-31 write block 1's
         if (LSEg != nullptr && g < 2) {
@@ -443,7 +452,8 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
 
 template <typename T, int D>
 int launch16(const void* q, const void* k, const void* v, void* o, float* lse,
-             int64_t heads, int64_t N, float scale, float thr, bool causal, hipStream_t s) {
+             int64_t heads, int64_t N, int64_t d, float scale, float thr, bool causal, hipStream_t s) {
+    if (N * d * 2 >= (int64_t)kPastEnd) return fail(MYFA_E_UNSUPPORTED, "attention: N*d=%lld per head too large", (long long)(N * d));
     const int64_t nqblk = cdiv(N, kBQ16);
     const int64_t nwg = heads * nqblk;
     if (nwg > 0x7fffffffLL) return fail(MYFA_E_UNSUPPORTED, "attention: too many workgroups (%lld)", (long long)nwg);
@@ -451,7 +461,7 @@ int launch16(const void* q, const void* k, const void* v, void* o, float* lse,
     auto go = [&](auto kern) {
         launch_kernel(kern, dim3((unsigned)nwg), dim3(kThreads16), 0, s,
                            static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
-                           static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, thr);
+                           static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, thr, (int)d);
     };
     if (causal) go(attn_fwd_mfma16_kernel<T, D, true>);
     else go(attn_fwd_mfma16_kernel<T, D, false>);
@@ -463,11 +473,15 @@ int launch16(const void* q, const void* k, const void* v, void* o, float* lse,
 // dtype: MYFA_F16 or MYFA_BF16; d: 64 or 128; heads = B*H; thr: deferred-max threshold (log2 units)
 int attn_fwd_mfma16(const void* q, const void* k, const void* v, void* o, float* lse,
                     int64_t heads, int64_t N, int64_t d, float scale, float thr, int dtype, bool causal, hipStream_t s) {
-    if (dtype == MYFA_BF16 && d == 128) return launch16<__bf16, 128>(q, k, v, o, lse, heads, N, scale, thr, causal, s);
-    if (dtype == MYFA_BF16 && d == 64)  return launch16<__bf16, 64>(q, k, v, o, lse, heads, N, scale, thr, causal, s);
-    if (dtype == MYFA_F16 && d == 128)  return launch16<_Float16, 128>(q, k, v, o, lse, heads, N, scale, thr, causal, s);
-    if (dtype == MYFA_F16 && d == 64)   return launch16<_Float16, 64>(q, k, v, o, lse, heads, N, scale, thr, causal, s);
-    return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16): head dim %lld not in {64, 128}", (long long)d);
+    // head dims that are multiples of 8 run on the next build up, the missing columns read as zeros
+    if (d >= 8 && d <= 128 && d % 8 == 0) {
+        const bool big = d > 64;
+        if (dtype == MYFA_BF16) return big ? launch16<__bf16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s)
+                                           : launch16<__bf16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s);
+        if (dtype == MYFA_F16)  return big ? launch16<_Float16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s)
+                                           : launch16<_Float16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s);
+    }
+    return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16): head dim %lld is not a multiple of 8 in 8..128", (long long)d);
 }
 
 }  // namespace myfa

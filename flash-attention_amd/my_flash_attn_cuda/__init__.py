@@ -204,7 +204,9 @@ def flash_attn_fwd(q, k, v, scale=1.0, return_lse=False, causal=False):
     or float32); k is NOT transposed.  scale defaults to 1.0, the reference's
     semantics (its tests compare against scaled_dot_product_attention(scale=1.0),
     tests/test_flash_attn.py:165,183); pass d ** -0.5 for the usual scaling.
-    float16/bfloat16 run on the matrix cores and need d in {64, 128}.
+    float16/bfloat16 run on the matrix cores for every head dim that is a multiple of 8 up to 128
+    (64 and 128 at full speed, the others on the next build up with zero columns); other head dims
+    take a detour through padded or float32 copies (see below) and float32 takes any d <= 512.
     With return_lse=True also returns the float32 (B, H, N) row log-sum-exp of the
     scaled logits (the m + log l statistic of tests/test_flash_attn.py:58-59,98-99).
     causal=True masks key j for query i when j > i, as
@@ -221,6 +223,18 @@ def flash_attn_fwd(q, k, v, scale=1.0, return_lse=False, causal=False):
     if q.dtype not in _DTYPE_TAG:
         raise RuntimeError(f"unsupported dtype {q.dtype}")
     B, H, N, d = q.shape
+    if q.dtype != torch.float32 and d > 0 and (d % 8 != 0 or d > 128):
+        # Outside what the matrix-core kernels take (head dims that are multiples of 8 up to 128):
+        # pad the head dim with zero columns up to the next multiple of 8 (the logits do not change,
+        # the extra output columns are dropped), or, beyond 128, run the float32 kernel (any d <= 512)
+        # on widened copies.  Both cost extra passes over q, k, v; neither changes the result's dtype.
+        if d <= 128:
+            pad = (-d) % 8
+            qp, kp, vp = (torch.nn.functional.pad(t, (0, pad)) for t in (q, k, v))
+            res = flash_attn_fwd(qp, kp, vp, scale=scale, return_lse=return_lse, causal=causal)
+            return (res[0][..., :d].contiguous(), res[1]) if return_lse else res[..., :d].contiguous()
+        res = flash_attn_fwd(q.float(), k.float(), v.float(), scale=scale, return_lse=return_lse, causal=causal)
+        return (res[0].to(q.dtype), res[1]) if return_lse else res.to(q.dtype)
     out = torch.empty_like(q)
     lse = torch.empty((B, H, N), dtype=torch.float32, device=q.device) if return_lse else None
     with _on(q):
@@ -233,7 +247,7 @@ def flash_attn_fwd(q, k, v, scale=1.0, return_lse=False, causal=False):
 
 def flash_attn_bwd(dout, q, k, v, out, lse, scale=1.0, causal=False):
     """Gradients (dq, dk, dv) of flash_attn_fwd for float16 / bfloat16 (B, H, N, d) tensors,
-    d in {64, 128}.  `out` and `lse` are the forward's results (return_lse=True), `dout` the
+    d <= 128 (64 and 128 natively, smaller ones through zero-padded copies).  `out` and `lse` are the forward's results (return_lse=True), `dout` the
     gradient of `out`.  The reference has no backward; this is the derivative of the forward
     it sketches (csrc/my_flash_attn/flash_attention.cu:23-69)."""
     for t, name in ((dout, "dout"), (q, "q"), (k, "k"), (v, "v"), (out, "out"), (lse, "lse")):
@@ -248,6 +262,11 @@ def flash_attn_bwd(dout, q, k, v, out, lse, scale=1.0, causal=False):
     B, H, N, d = q.shape
     if lse.dtype != torch.float32 or tuple(lse.shape) != (B, H, N):
         raise RuntimeError("lse must be the float32 (B, H, N) tensor returned by flash_attn_fwd")
+    if d not in (64, 128) and 0 < d < 128:
+        # the backward kernels exist for d = 64 and 128: zero columns up to there change nothing
+        pad = (64 if d < 64 else 128) - d
+        padded = [torch.nn.functional.pad(t, (0, pad)) for t in (dout, q, k, v, out)]
+        return tuple(g[..., :d].contiguous() for g in flash_attn_bwd(*padded, lse, scale=scale, causal=causal))
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     delta = torch.empty((2, B, H, N), dtype=torch.float32, device=q.device)   # workspace: -rowsum(dout * out), lse in base 2
     with _on(q):

@@ -194,9 +194,12 @@ def test_memory_behind_the_tensors_never_reaches_the_output(mfa, dtype, d, N):
 
 
 def test_bhnd_errors(mfa):
-    q = torch.randn(1, 2, 64, 96, device="cuda", dtype=torch.bfloat16)
-    with pytest.raises(RuntimeError, match="head dim"):
-        mfa.flash_attn_fwd(q, q, q)
+    from my_flash_attn_cuda import _lib
+    q = torch.randn(1, 2, 64, 100, device="cuda", dtype=torch.bfloat16)     # not a multiple of 8: the C ABI refuses,
+    rc = _lib.lib.myfa_attn_fwd_bhnd(q.data_ptr(), q.data_ptr(), q.data_ptr(), q.data_ptr(), None, 1, 2, 64, 100,
+                                     1.0, _lib.MYFA_BF16, None)
+    assert rc == 2 and b"head dim" in _lib.lib.myfa_last_error()
+    assert mfa.flash_attn_fwd(q, q, q, scale=0.1).shape == q.shape             # the host layer pads
     q = torch.randn(1, 2, 64, 64, device="cuda", dtype=torch.bfloat16)
     with pytest.raises(RuntimeError, match="scale"):
         mfa.flash_attn_fwd(q, q, q, scale=-1.0)

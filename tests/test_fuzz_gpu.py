@@ -35,11 +35,14 @@ def _cases(seed, count, dims):
     return out
 
 
-@pytest.mark.parametrize("case", _cases(11, 24, [64, 128]))
+# 64 and 128 are the native builds; 8..120 in steps of 8 run on them with zero columns; the
+# reference's own odd head dims (tests/test_flash_attn.py:155: 1, 2, 20, 63, 65, 99) and 256 go
+# through the host layer's padded / float32 detours
+@pytest.mark.parametrize("case", _cases(11, 24, [64, 128]) + _cases(15, 28, [8, 32, 40, 96, 104, 120, 256, 1, 2, 20, 63, 65, 99]))
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_fuzz_forward_lowp(mfa, dtype, case):
     B, H, N, d, causal, scale, seed = case
-    if scale == 1.0 and d == 128:
+    if scale == 1.0 and d >= 96:
         scale = 0.25          # unscaled logits at d = 128 saturate the softmax; covered by the fixed-shape tests
     torch.manual_seed(seed)
     q, k, v = (torch.randn(B, H, N, d) for _ in range(3))
@@ -60,7 +63,7 @@ def test_fuzz_forward_f32(mfa, case):
     assert np.abs(lse.cpu().numpy() - ref_cpu.attention_lse(q.numpy(), k.numpy(), scale=scale * 0.5, causal=causal)).max() <= 1e-5
 
 
-@pytest.mark.parametrize("case", _cases(13, 16, [64, 128]))
+@pytest.mark.parametrize("case", _cases(13, 16, [64, 128]) + _cases(16, 8, [32, 96, 40]))
 def test_fuzz_backward(mfa, case):
     B, H, N, d, causal, _, seed = case
     scale = d ** -0.5
