@@ -475,11 +475,14 @@ attn_fwd_mfma_pp_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
         float a = vmax3(s[0][0], s[0][1], s[0][2]), b = vmax3(s[1][0], s[1][1], s[1][2]);
 #pragma unroll
         for (int i = 3; i < 15; i += 2) { a = vmax3(a, s[0][i], s[0][i + 1]); b = vmax3(b, s[1][i], s[1][i + 1]); }
-        const HalfPair hp = both_halves(vmax3(a, b, vmax2(s[0][15], s[1][15])));
-        const float tmax = vmax2(hp.lo, hp.hi);
-        const float mt = tmax * sl2;
+        const float tloc = vmax3(a, b, vmax2(s[0][15], s[1][15]));
         if constexpr (STAMP) s1 = stamp();
-        if (__builtin_amdgcn_ballot_w64(mt - m > thr) != 0) {   // wave-uniform
+        // a row's max grows past the threshold exactly when one of its two lanes' partial maxima
+        // does: the lanes vote on their own 32 logits, the half exchange happens only in the (rare)
+        // tile where the vote says the running max has to move
+        if (__builtin_amdgcn_ballot_w64(__builtin_fmaf(tloc, sl2, -m) > thr) != 0) {   // wave-uniform
+            const HalfPair hp = both_halves(tloc);
+            const float mt = vmax2(hp.lo, hp.hi) * sl2;
             const float m_new = fmaxf(m, mt);
             const float alpha = __builtin_amdgcn_exp2f(m - m_new);
             m = m_new;
