@@ -61,7 +61,12 @@ template <int NB> constexpr int max_waves() { return NB <= 4 ? 16 : NB <= 8 ? 8 
 // my_attention layout) instead of [N, d].  VEC: d % 4 == 0 and all bases 16-byte aligned, so rows
 // are read and written as float4; otherwise element by element.
 // CAUSAL: key j is visible to query i only if j <= i (batched entry point only).
-template <int NB, bool KT, bool VEC, bool CAUSAL = false>
+// FAST (needs VEC, K as [N, d], d == 16 NB, a head below 2 GiB, NB <= 8): K and V rows come through
+// buffer loads -- rows past N read as zero by the bounds check, so the loop has no row clamp, no
+// column guard and no 64-bit address arithmetic (those were 16 exec-masked branches and ~150 of
+// the ~380 instructions of a tile).
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+template <int NB, bool KT, bool VEC, bool CAUSAL = false, bool FAST = false>
 __global__ void __launch_bounds__(max_waves<NB>() * 64)
 attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
                     const float* __restrict__ Vg, float* __restrict__ Og, float* __restrict__ LSEg,
@@ -129,10 +134,25 @@ attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
 
     // (rows past N are masked in the softmax; the clamp only keeps the address valid)
     [[maybe_unused]] f32x4 kf[PREFETCH ? NB : 1];
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t krs, vrs;
+    [[maybe_unused]] int k_voff = 0, v_voff = 0;
+    if constexpr (FAST) {
+        const unsigned head_bytes = (unsigned)N * (unsigned)d * 4u;
+        krs = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, head_bytes, 0x00020000);
+        vrs = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, head_bytes, 0x00020000);
+        k_voff = (j * d + 4 * g) * 4;            // K[key0 + j][16 b + 4 g ..]: + 64 b, + key0 * d * 4
+        v_voff = (g * d + 4 * j) * 4;            // V[key0 + 4 r + g][64 bb + 4 j ..]: + 256 bb, + (key0 + 4 r) * d * 4
+    }
     auto load_k = [&](int kt) __attribute__((always_inline)) {
-        const int key = min(kt * 16 + j, N - 1);
+        if constexpr (FAST) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) kf[b] = k4(key, 16 * b + 4 * g);
+            for (int b = 0; b < NB; ++b)
+                kf[b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, k_voff + 64 * b, kt * 16 * d * 4, 0));
+        } else {
+            const int key = min(kt * 16 + j, N - 1);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) kf[b] = k4(key, 16 * b + 4 * g);
+        }
     };
     if constexpr (PREFETCH) load_k(max(min(t0 + split, ntiles - 1), 0));
 
@@ -140,7 +160,13 @@ attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
         const int key0 = kt * 16;
         // ---- V of this tile is requested now and consumed after the logits
         [[maybe_unused]] f32x4 vf[PREFETCH ? 4 : 1][PREFETCH ? NBB : 1];
-        if constexpr (PREFETCH) {
+        if constexpr (FAST) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int bb = 0; bb < NBB; ++bb)
+                    vf[r][bb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, v_voff + 256 * bb, (key0 + 4 * r) * d * 4, 0));
+        } else if constexpr (PREFETCH) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float* vrow = Vh + min(key0 + 4 * r + g, N - 1) * d;
@@ -152,14 +178,20 @@ attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
         // ---- S^T tile: float64 MFMA over the head dim
         f64x4 c = {0.0, 0.0, 0.0, 0.0};
         if constexpr (PREFETCH) {
+            // two accumulation chains: a float64 MFMA that waits for the one before it leaves the
+            // matrix pipe idle for the difference between its latency and its issue time
+            f64x4 c2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int b = 0; b < NB; ++b)
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; t += 2) {
                     c = __builtin_amdgcn_mfma_f64_16x16x4f64((double)kf[b][t], (double)qv[b][t], c, 0, 0, 0);
+                    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)kf[b][t + 1], (double)qv[b][t + 1], c2, 0, 0, 0);
+                }
+            c += c2;
             // K of this wave's next tile goes into the registers just consumed; its latency
             // is covered by the softmax and the P.V product below
-            load_k(min(kt + KS, ntiles - 1));
+            load_k(FAST ? kt + KS : min(kt + KS, ntiles - 1));   // (FAST: a tile past the end reads zeros)
         } else {
             const int key = min(key0 + j, N - 1);
 #pragma unroll
@@ -317,7 +349,10 @@ template <int NB, bool KT, bool VEC, bool CAUSAL = false>
 int launch(const float* q, const float* k, const float* v, float* o, float* lse,
            int64_t heads, int64_t N, int64_t d, float scale, hipStream_t s,
            float* ws = nullptr, size_t ws_bytes = 0) {
-    auto kern = attn_fwd_f32_kernel<NB, KT, VEC, CAUSAL>;
+    constexpr bool can_fast = VEC && !KT && NB <= 8;
+    const bool fast = can_fast && d == 16 * NB && N * d * 4 < (1LL << 31);
+    auto kern = attn_fwd_f32_kernel<NB, KT, VEC, CAUSAL, false>;
+    if constexpr (can_fast) { if (fast) kern = attn_fwd_f32_kernel<NB, KT, VEC, CAUSAL, true>; }
     constexpr int wmax = max_waves<NB>();
     const int64_t qgroups = cdiv(N, 16);
     const int64_t ntiles = cdiv(N, 16);

@@ -188,7 +188,7 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
     vec8 qf[2][KS];
     vec8 pb[2][2];
 
-    constexpr int NQ = 4 * KS, NP = 2 * DB, FW = D == 64 ? 4 : 8;
+    constexpr int NQ = 4 * KS, NP = 2 * DB, FW = D == 64 ? 4 : 8;   // (4, 6 and 12 at D = 128: 3-6 % more cycles)
     // fragment i of the matrix phase: i < NQ: K fragment (kb = i / KS, ks = i % KS) of the K slot;
     // otherwise V fragment (st, db) of the V slot.  Each fragment feeds two MFMAs (qb = 0, 1).
     // kaddr / vaddr[2]: per-lane base plus ring slot, formed once per phase (`slot_addr`); the
