@@ -8,10 +8,10 @@ tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_$tag
 mkdir -p "$out"
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o bench -- python3 bench.py --steps 20 --warmup 3 --no-extras > "$out/bench_under_rocprof.json" 2> "$out/bench_under_rocprof.err"
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o bench -- python3 bench.py --steps 200 --warmup 3 --no-extras > "$out/bench_under_rocprof.json" 2> "$out/bench_under_rocprof.err"
 rc=$?; echo "bench under rocprofv3 rc=$rc"
 [ $rc -ne 0 ] && { tail -5 "$out/bench_under_rocprof.err"; exit $rc; }
-python3 tools/trace_timed_avg.py "$out/bench_kernel_trace.csv" 20 > "$out/attn_headline_timed_launches.txt"; cat "$out/attn_headline_timed_launches.txt"
+python3 tools/trace_timed_avg.py "$out/bench_kernel_trace.csv" 200 > "$out/attn_headline_timed_launches.txt"; cat "$out/attn_headline_timed_launches.txt"
 timeout -k 10 600 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
 rc=$?; echo "plain bench rc=$rc"
 [ $rc -ne 0 ] && { tail -5 "$out/bench.err"; exit $rc; }
