@@ -416,10 +416,21 @@ def main():
         log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
+    # Rank 0's stdout carries exactly one line, the JSON.  RCCL prints a version banner to the
+    # process's stdout when the first communicator is built, so file descriptor 1 points at stderr
+    # until the JSON line is due.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     if use_dist:
         if args.force_dist and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # The first collective builds the communicator (hundreds of ms).  Done here, untimed, so that
+        # the barrier in front of the timed steps is a short one: a GPU left idle for that long
+        # drops its clocks, and the first ~10 ms of launches after it would run slow.
+        dist.barrier()
+        torch.cuda.synchronize()
 
     import my_flash_attn_cuda as mfa   # raises if the HIP library is not built
 
@@ -493,6 +504,9 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(result), flush=True)
 

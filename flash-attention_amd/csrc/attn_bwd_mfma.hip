@@ -57,8 +57,13 @@ attn_bwd_delta_kernel(const T* __restrict__ Og, const T* __restrict__ dOg, const
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc += (float)a[j] * (float)b[j];
     }
-#pragma unroll
-    for (int m = 1; m < CPR; m <<= 1) acc += __shfl_xor(acc, m);
+    // sum over the CPR (8 or 16) adjacent lanes of a row, on DPP: xor 1, xor 2 inside quads, then the
+    // mirrored quad of the 8-lane group, then the mirrored half of the 16-lane row
+    acc += dpp_mov<0xB1>(acc);
+    acc += dpp_mov<0x4E>(acc);
+    acc += dpp_mov<0x141>(acc);
+    if constexpr (CPR == 16) acc += dpp_mov<0x140>(acc);
+    static_assert(CPR == 8 || CPR == 16, "row sum written for 8 or 16 lanes per row");
     if (row < rows && ch == 0) {
         DELg[row] = -acc;
         DELg[rows + row] = LSEg[row] * kLog2e;
