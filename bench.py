@@ -56,7 +56,7 @@ import torch.distributed as dist  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/f16 MFMA peak, MI355X
 HBM_PEAK_GBS = 8000.0       # HBM3E peak
-PRIMING = 20                # untimed launches before the warm-up steps
+PRIMING = 100               # untimed launches before the warm-up steps (the clocks settle over ~55 launches, ~50 ms)
 
 WORKLOADS = {
     # name: (B, H, N, d, dtype) -- per GPU
@@ -78,8 +78,11 @@ def attn_flops(B, H, N, d, causal=False):
 def bench_attention(mfa, B, H, N, d, dtype, steps, warmup, world, scale, causal=False, use_dist=False):
     torch.manual_seed(1 + int(os.environ.get("RANK", "0")))
     q, k, v = (torch.randn(B, H, N, d, dtype=dtype, device="cuda") for _ in range(3))
-    # Untimed: PRIMING launches bring the clocks and caches to their running state whatever W is
-    # (the first ~10 ms after idle run at a lower clock), then the W warm-up steps of the contract.
+    # Untimed: PRIMING launches bring the clocks and caches to their running state whatever W is,
+    # then the W warm-up steps of the contract.  From idle the kernel takes 0.90, 1.06, 1.21 ms for
+    # its first launches and then comes down slowly -- 0.92 ms at launch 20, 0.89 at 30, 0.87 from
+    # launch ~55 on, where it stays (kernel trace of 223 launches, profiles/) -- so fewer priming
+    # launches would time the power management's transient, not the kernel.
     for _ in range(PRIMING):
         out = mfa.flash_attn_fwd(q, k, v, scale=scale, causal=causal)
     for _ in range(warmup):
