@@ -9,11 +9,20 @@
 // a Q tile resident and streams K/V tiles past it, with O left un-normalised in
 // registers until one final division by l.
 //
-// Work decomposition
-//   workgroup = 8 waves = 256 query rows of one (batch, head); wave w owns rows
-//   32w..32w+31.  K/V are streamed in tiles of 64 keys, register-staged
-//   (global_load_dwordx4 issued one tile ahead, ds_write_b128 after the MFMAs)
-//   into a double-buffered LDS image; one barrier per tile.
+// Two kernels in this file, both on v_mfma_f32_32x32x16 (the 16x16x32 build of the same design is
+// attn_fwd_mfma16.hip; the launcher at the bottom picks between them):
+//   attn_fwd_mfma_pp_kernel  the one that ships for the causal mask: K/V tiles fetched by LDS-DMA
+//                            (buffer_load ... lds) into rings of 4 / 3 slots, the two waves of a
+//                            SIMD in opposite phases (matrix / softmax), one s_barrier per phase.
+//                            Described in the comment in front of it.
+//   attn_fwd_mfma_kernel     the first schedule, kept for cross-checks (only the tuning flavour can select it): tiles
+//                            staged through registers (global_load_dwordx4 one tile ahead,
+//                            ds_write_b128 behind the MFMAs) into a double buffer with per-row XOR
+//                            swizzles (k_off / v_off below), one barrier per tile.
+//
+// Work decomposition (both)
+//   workgroup = 8 waves = 256 query rows of one (batch, head); wave w owns rows 32w..32w+31.
+//   K/V are streamed in tiles of 64 keys.
 //
 // Register choreography (v_mfma_f32_32x32x16: D[32x32] += A[32x16] B[16x32])
 //   S^T = K Q^T : A = K rows (keys), B = Q^T, so the accumulator has the QUERY on
@@ -27,10 +36,6 @@
 //   read from the row-major V tile with the transposing LDS read
 //   ds_read_b64_tr_b16 in that same key order.  O^T again has the query on the
 //   lane, so the per-row rescale and the final 1/l are per-lane scalars.
-//
-// LDS images (bank-conflict-free for the reads that use them)
-//   K tile [64][D]: 16-byte chunk c of row r at  r*2D + 16*(c ^ swzK(r))   (ds_read_b128 rows)
-//   V tile [64][D]: chunk c of row r at          r*2D + 16*(c ^ swzV(r))   (transposing reads)
 #include "attn_mfma_common.h"
 #include "tuning.h"
 
