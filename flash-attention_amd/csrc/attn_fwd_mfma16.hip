@@ -285,12 +285,22 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
             b = vmax3(b, s[3][qb][1], s[3][qb][2]);
             tmax[qb] = vmax3(a, b, vmax2(s[1][qb][3], s[3][qb][3]));
         }
-        const Pair mt_ = four_row_reduce(tmax[0], tmax[1], RawMaxOp{});
-        const float mt[2] = {mt_.a * sl2, mt_.b * sl2};
-        // (The exchange could wait for the tile in which some lane's own partial maximum passes the
-        // threshold -- the 32x32x16 build does that.  Measured here: 12 fewer instructions per tile
-        // and 3.6 % MORE cycles, the compiler's schedule of the phase changes with them.)
+        // A row's max passes the threshold exactly when one of its four lanes' partial maxima does,
+        // so the lanes can vote on their own 16 logits and leave the exchange between the four lanes
+        // of a row to the (rare) tile in which the running max has to move: 12 instructions fewer per
+        // tile.  Measured: at D = 64, where the vector issue port is the bound, that is what it saves;
+        // at D = 128 the kernel takes 3.6 % MORE cycles with it (the compiler's schedule of the phase
+        // changes), so there the exchange stays in front of the vote.
+        constexpr bool LAZY = D == 64;
+        Pair mt_ = {tmax[0], tmax[1]};
+        if constexpr (!LAZY) mt_ = four_row_reduce(tmax[0], tmax[1], RawMaxOp{});
+        float mt[2] = {mt_.a * sl2, mt_.b * sl2};
         if (__builtin_amdgcn_ballot_w64((mt[0] - m[0] > thr) || (mt[1] - m[1] > thr)) != 0) {   // wave-uniform
+            if constexpr (LAZY) {
+                mt_ = four_row_reduce(tmax[0], tmax[1], RawMaxOp{});
+                mt[0] = mt_.a * sl2;
+                mt[1] = mt_.b * sl2;
+            }
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 const float m_new = fmaxf(m[qb], mt[qb]);
