@@ -211,9 +211,10 @@ def bench_softmax_sweep(mfa, iters=20):
 
 
 def bench_softmax_dim(mfa):
-    """softmax along a non-last dimension: register-resident column blocks and streamed columns."""
+    """softmax along a non-last dimension: register-resident column blocks, streamed columns, and tall
+    narrow tensors (rows of a column block split over workgroups)."""
     res = []
-    for shape, dim in (((256, 64, 64, 64), 1), ((64, 128, 16384), 1), ((8192, 8192), 0)):
+    for shape, dim in (((256, 64, 64, 64), 1), ((64, 128, 16384), 1), ((8192, 8192), 0), ((16384, 4096), 0), ((100000, 512), 0)):
         xs = [torch.randn(*shape, dtype=torch.float32, device="cuda") for _ in range(3)]
         i = [0]
 

@@ -45,7 +45,9 @@ int softmax_f32(const float* in, float* out, int64_t h, int64_t w, hipStream_t s
 int softmax_rows(const void* in, void* out, int64_t h, int64_t w, int dtype, hipStream_t s);
 int softmax_strided(const void* in, void* out, int64_t outer, int64_t len, int64_t inner, int dtype, hipStream_t s);
 int softmax_strided_pro(const void* in, void* out, int64_t outer, int64_t len, int64_t inner, int dtype,
-                        float scale, const float* mask, int64_t mask_outer, bool causal, hipStream_t s);
+                        float scale, const float* mask, int64_t mask_outer, bool causal, hipStream_t s,
+                        void* ws, size_t ws_bytes);
+size_t softmax_strided_ws_bytes(int64_t outer, int64_t len, int64_t inner, int dtype);
 int matmul_f32(const float* a, const float* b, float* c, int64_t m, int64_t k, int64_t n, hipStream_t s);
 int attn_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse,
                  int64_t heads, int64_t N, int64_t d, int64_t k_key_stride, int64_t k_d_stride,
@@ -100,7 +102,22 @@ int myfa_softmax_nd_ex(const void* in, void* out, int64_t outer, int64_t len, in
                        float scale, const float* add_mask, int64_t mask_outer, int flags, void* stream) {
     if ((flags & ~MYFA_SOFTMAX_CAUSAL) != 0) return fail(MYFA_E_INVALID, "softmax: unknown flag bits 0x%x", flags);
     return softmax_strided_pro(in, out, outer, len, inner, dtype, scale, add_mask, mask_outer,
-                               (flags & MYFA_SOFTMAX_CAUSAL) != 0, static_cast<hipStream_t>(stream));
+                               (flags & MYFA_SOFTMAX_CAUSAL) != 0, static_cast<hipStream_t>(stream), nullptr, 0);
+}
+
+int64_t myfa_softmax_nd_ws_bytes(int64_t outer, int64_t len, int64_t inner, int dtype) {
+    return (int64_t)softmax_strided_ws_bytes(outer, len, inner, dtype);
+}
+
+int myfa_softmax_nd_ws(const void* in, void* out, int64_t outer, int64_t len, int64_t inner, int dtype,
+                       float scale, const float* add_mask, int64_t mask_outer, int flags,
+                       void* workspace, int64_t workspace_bytes, void* stream) {
+    if ((flags & ~MYFA_SOFTMAX_CAUSAL) != 0) return fail(MYFA_E_INVALID, "softmax: unknown flag bits 0x%x", flags);
+    if (workspace_bytes < 0 || (workspace == nullptr && workspace_bytes > 0) || reinterpret_cast<uintptr_t>(workspace) % 16 != 0)
+        return fail(MYFA_E_INVALID, "softmax: workspace must be 16-byte aligned with a non-negative size");
+    return softmax_strided_pro(in, out, outer, len, inner, dtype, scale, add_mask, mask_outer,
+                               (flags & MYFA_SOFTMAX_CAUSAL) != 0, static_cast<hipStream_t>(stream),
+                               workspace, (size_t)workspace_bytes);
 }
 
 int myfa_attn_fwd_f32(const float* q, const float* k_t, const float* v, float* o,
@@ -207,7 +224,7 @@ int myfa_matmul_f32(const float* a, const float* b, float* c, int64_t m, int64_t
 #ifdef MYFA_TUNING
 // Exported by the tuning flavour only (not part of include/myfa.h).  Keys: attn_variant,
 // attn_thr, attn_bq, matmul_block, softmax_tpr, softmax_v, softmax_map, softmax_nt, softmax_pad,
-// reset (back to the defaults).  Returns 0, or 1 for an unknown key.
+// softmax_split_wgs, reset (back to the defaults).  Returns 0, or 1 for an unknown key.
 int myfa_tuning_set(const char* key, double value) {
     Tuning& t = tuning();
     const std::string k(key ? key : "");
@@ -222,6 +239,7 @@ int myfa_tuning_set(const char* key, double value) {
     else if (k == "softmax_map") t.softmax_shape[2] = (int)value;
     else if (k == "softmax_nt") t.softmax_shape[3] = (int)value;
     else if (k == "softmax_pad") t.softmax_shape[4] = (int)value;
+    else if (k == "softmax_split_wgs") t.softmax_split_wgs = (int)value;
     else return fail(MYFA_E_INVALID, "tuning: unknown key '%s'", k.c_str());
     return MYFA_OK;
 }

@@ -13,7 +13,9 @@
 //   softmax_cols_stream   any len: online (max, sum) pass, then a pass that re-reads and writes
 //                         (256 threads, or 512 / 1024 for long columns)
 // VW = 4 floats or 8 halves needs inner % VW == 0 and 16-byte aligned bases; otherwise VW = 1.
+#include <algorithm>
 #include "softmax_common.h"
+#include "tuning.h"
 
 namespace myfa {
 int softmax_rows(const void* in, void* out, int64_t h, int64_t w, int dtype, hipStream_t s);
@@ -105,78 +107,146 @@ softmax_cols_reg(const E* __restrict__ in, E* __restrict__ out, int64_t len, int
     }
 }
 
+__device__ __forceinline__ void put(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float get(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // Any len: BLOCK = 256, 512 or 1024 threads, rows taken U at a time per thread so that U loads are in
 // flight and the running max is refreshed once per U rows.
-template <typename E, int TX, int VW, int BLOCK, bool PRO = false>
+//   PHASE 0: one workgroup per column block does both passes (grid = column blocks).
+// With a workspace the rows of a column block are also split over `nsplit` workgroups, in two launches
+// (grid = column blocks x nsplit, column block fastest so that workgroups running side by side
+// read different columns):
+//   PHASE 1: (max, sum) of the workgroup's rows -> part[block][split][2][TX * VW]; the workgroup of a
+//            column block that finishes last (a counter per block, zero at launch) merges the block's
+//            nsplit pairs into fin[block][2][TX * VW].  Nobody waits for anybody.
+//   PHASE 2: re-reads its rows and writes, with the column block's (max, sum) from fin; the launch
+//            walks the tensor from its end, starting on what phase 1 read last.
+// The pairs cross workgroups inside phase 1, so they are written and read with device-scope accesses
+// (past the per-XCD L2s) and need no cache-wide write-back or invalidate.
+template <typename E, int TX, int VW, int BLOCK, bool PRO = false, int PHASE = 0>
 __global__ void __launch_bounds__(BLOCK)
-softmax_cols_stream(const E* __restrict__ in, E* __restrict__ out, int64_t len, int64_t inner, int64_t nchunk, Prologue pro) {
-    constexpr int TY = BLOCK / TX, U = VW == 8 ? 2 : 4;
+softmax_cols_stream(const E* __restrict__ in, E* __restrict__ out, int64_t len, int64_t inner, int64_t nchunk, Prologue pro,
+                    int64_t groups, int nsplit, int64_t rows_per_split, unsigned* __restrict__ count, float* __restrict__ stats) {
+    constexpr int TY = BLOCK / TX, U = VW == 8 ? 2 : 4, W = TX * VW;
     __shared__ float red[BLOCK * VW];
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-    const int64_t o = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+    const int64_t id = PHASE == 2 ? (int64_t)gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const int64_t group = PHASE == 0 ? id : id % groups;
+    const int split = PHASE == 0 ? 0 : (int)(id / groups);
+    const int64_t o = group / nchunk, chunk = group % nchunk;
     const int64_t col = (chunk * TX + tx) * VW;
     const bool live = col < inner;
+    const int64_t row_begin = PHASE == 0 ? 0 : split * rows_per_split;
+    const int64_t row_end = PHASE == 0 ? len : (row_begin + rows_per_split < len ? row_begin + rows_per_split : len);
     const E* src = in + o * len * inner + col;
     E* dst = out + o * len * inner + col;
 
-    // pass 1: per-thread online (max, sum of 2^((x - max) * log2e)) of each of its VW columns
-    float mx[VW], sum[VW];
+    float mx[VW], sum[VW], cmx[VW];
+    if constexpr (PHASE != 2) {
+        // pass 1: per-thread online (max, sum of 2^((x - max) * log2e)) of each of its VW columns
 #pragma unroll
-    for (int c = 0; c < VW; ++c) { mx[c] = -INFINITY; sum[c] = 0.f; }
-    if (live) {
-        for (int64_t row0 = ty; row0 < len; row0 += (int64_t)U * TY) {
-            float x[U][VW];
+        for (int c = 0; c < VW; ++c) { mx[c] = -INFINITY; sum[c] = 0.f; }
+        if (live) {
+            for (int64_t row0 = row_begin + ty; row0 < row_end; row0 += (int64_t)U * TY) {
+                float x[U][VW];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t row = row0 + (int64_t)u * TY;
-                if (row < len) {
-                    vload<E, VW, false>(x[u], src + row * inner);
-                    if constexpr (PRO) prologue_col<VW>(x[u], pro, o, len, inner, row, col);
-                } else {
+                for (int u = 0; u < U; ++u) {
+                    const int64_t row = row0 + (int64_t)u * TY;
+                    if (row < row_end) {
+                        vload<E, VW, false>(x[u], src + row * inner);
+                        if constexpr (PRO) prologue_col<VW>(x[u], pro, o, len, inner, row, col);
+                    } else {
 #pragma unroll
-                    for (int c = 0; c < VW; ++c) x[u][c] = -INFINITY;
+                        for (int c = 0; c < VW; ++c) x[u][c] = -INFINITY;
+                    }
                 }
-            }
 #pragma unroll
-            for (int c = 0; c < VW; ++c) {
-                float cm = x[0][c];
+                for (int c = 0; c < VW; ++c) {
+                    float cm = x[0][c];
 #pragma unroll
-                for (int u = 1; u < U; ++u) cm = fmaxf(cm, x[u][c]);
-                if (cm > mx[c]) {
-                    sum[c] *= __builtin_amdgcn_exp2f((mx[c] - cm) * kLog2e);   // mx = -inf first time: sum is 0
-                    mx[c] = cm;
-                }
-                // rows past the end hold -inf and add 0.  While everything seen of a column is -inf
-                // there is nothing to add: (-inf) - (-inf) is NaN and would survive the later rescale
-                // by 0 (leading -inf rows are ordinary input: a causal mask along this dimension); only
-                // a column that is -inf throughout comes out NaN, through 0 * inf in the second pass
-                if (mx[c] != -INFINITY) {
+                    for (int u = 1; u < U; ++u) cm = fmaxf(cm, x[u][c]);
+                    if (cm > mx[c]) {
+                        sum[c] *= __builtin_amdgcn_exp2f((mx[c] - cm) * kLog2e);   // mx = -inf first time: sum is 0
+                        mx[c] = cm;
+                    }
+                    // rows past the end hold -inf and add 0.  While everything seen of a column is -inf
+                    // there is nothing to add: (-inf) - (-inf) is NaN and would survive the later rescale
+                    // by 0 (leading -inf rows are ordinary input: a causal mask along this dimension); only
+                    // a column that is -inf throughout comes out NaN, through 0 * inf in the second pass
+                    if (mx[c] != -INFINITY) {
 #pragma unroll
-                    for (int u = 0; u < U; ++u) sum[c] += __builtin_amdgcn_exp2f((x[u][c] - mx[c]) * kLog2e);
+                        for (int u = 0; u < U; ++u) sum[c] += __builtin_amdgcn_exp2f((x[u][c] - mx[c]) * kLog2e);
+                    }
                 }
             }
         }
     }
-    float cmx[VW];
+    float* fin = stats + group * 2 * W + tx * VW;                         // (phases 1, 2)
+    if constexpr (PHASE != 2) {
 #pragma unroll
-    for (int c = 0; c < VW; ++c) cmx[c] = mx[c];
-    column_reduce<TX, TY, VW>(cmx, red, tx, ty, MaxOp{});
-    // threads that saw no row have mx = -inf, sum = 0: they contribute 0
+        for (int c = 0; c < VW; ++c) cmx[c] = mx[c];
+        column_reduce<TX, TY, VW>(cmx, red, tx, ty, MaxOp{});
+        // threads that saw no row have mx = -inf, sum = 0: they contribute 0
 #pragma unroll
-    for (int c = 0; c < VW; ++c)
-        sum[c] = (mx[c] == -INFINITY) ? 0.f : sum[c] * __builtin_amdgcn_exp2f((mx[c] - cmx[c]) * kLog2e);
-    column_reduce<TX, TY, VW>(sum, red, tx, ty, SumOp{});
+        for (int c = 0; c < VW; ++c)
+            sum[c] = (mx[c] == -INFINITY) ? 0.f : sum[c] * __builtin_amdgcn_exp2f((mx[c] - cmx[c]) * kLog2e);
+        column_reduce<TX, TY, VW>(sum, red, tx, ty, SumOp{});
+    } else {
+#pragma unroll
+        for (int c = 0; c < VW; ++c) { cmx[c] = fin[c]; sum[c] = fin[W + c]; }
+    }
+
+    if constexpr (PHASE == 1) {
+        float* part = stats + (groups + group * (int64_t)nsplit) * 2 * W + tx * VW;
+        if (ty == 0) {
+#pragma unroll
+            for (int c = 0; c < VW; ++c) {
+                put(part + (int64_t)split * 2 * W + c, cmx[c]);
+                put(part + (int64_t)split * 2 * W + W + c, sum[c]);
+            }
+        }
+        __shared__ unsigned s_last;
+        __syncthreads();       // (waits for the stores above to have completed)
+        if (threadIdx.x == 0)
+            s_last = __hip_atomic_fetch_add(count + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nsplit - 1);
+        __syncthreads();
+        if (!s_last) return;   // uniform over the workgroup
+#pragma unroll
+        for (int c = 0; c < VW; ++c) { mx[c] = -INFINITY; sum[c] = 0.f; }
+        for (int sp = ty; sp < nsplit; sp += TY) {
+#pragma unroll
+            for (int c = 0; c < VW; ++c) {
+                const float pm = get(part + (int64_t)sp * 2 * W + c), pl = get(part + (int64_t)sp * 2 * W + W + c);
+                const float nm = fmaxf(mx[c], pm);
+                if (nm != -INFINITY)
+                    sum[c] = sum[c] * __builtin_amdgcn_exp2f((mx[c] - nm) * kLog2e) + pl * __builtin_amdgcn_exp2f((pm - nm) * kLog2e);
+                mx[c] = nm;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < VW; ++c) cmx[c] = mx[c];
+        column_reduce<TX, TY, VW>(cmx, red, tx, ty, MaxOp{});
+#pragma unroll
+        for (int c = 0; c < VW; ++c)
+            sum[c] = (mx[c] == -INFINITY) ? 0.f : sum[c] * __builtin_amdgcn_exp2f((mx[c] - cmx[c]) * kLog2e);
+        column_reduce<TX, TY, VW>(sum, red, tx, ty, SumOp{});
+        if (ty == 0) {
+#pragma unroll
+            for (int c = 0; c < VW; ++c) { fin[c] = cmx[c]; fin[W + c] = sum[c]; }
+        }
+        return;
+    }
 
     // pass 2: re-read (what is still in L2 / Infinity Cache comes from there) and write
     if (live) {
 #pragma unroll
         for (int c = 0; c < VW; ++c) sum[c] = 1.0f / sum[c];
-        for (int64_t row0 = ty; row0 < len; row0 += (int64_t)U * TY) {
+        for (int64_t row0 = row_begin + ty; row0 < row_end; row0 += (int64_t)U * TY) {
             float x[U][VW];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t row = row0 + (int64_t)u * TY;
-                if (row < len) {
+                if (row < row_end) {
                     vload<E, VW>(x[u], src + row * inner);
                     if constexpr (PRO) prologue_col<VW>(x[u], pro, o, len, inner, row, col);
                 }
@@ -184,7 +254,7 @@ softmax_cols_stream(const E* __restrict__ in, E* __restrict__ out, int64_t len, 
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t row = row0 + (int64_t)u * TY;
-                if (row < len) {
+                if (row < row_end) {
 #pragma unroll
                     for (int c = 0; c < VW; ++c) x[u][c] = __builtin_amdgcn_exp2f((x[u][c] - cmx[c]) * kLog2e) * sum[c];
                     vstore<E, VW>(dst + row * inner, x[u]);
@@ -199,47 +269,118 @@ softmax_cols_stream(const E* __restrict__ in, E* __restrict__ out, int64_t len, 
 //    row-segment width TX >= 8 items that still gives the chip enough workgroups -- the widest such
 //    TX -- or the tensor is small anyway; 4-item segments (64 bytes, half an L2 line) only for rows
 //    that narrow.
+//  * Otherwise, with a workspace and too few column blocks for the chip, the rows of a column block
+//    are split over workgroups as well (two launches, same traffic as the streamed form).
 //  * Otherwise streamed: 1024 threads for long columns, the widest TX that leaves one workgroup
 //    per CU; never narrower than 8 items (128 bytes, an L2 line) when the row has them.
-template <typename E, int VW, bool PRO>
-void launch_cols(const E* in, E* out, int64_t outer, int64_t len, int64_t inner, const Prologue& pro, hipStream_t s) {
+// TX of the register-resident kernel for this shape, 0 when it does not apply
+template <int VW>
+int reg_tx(int64_t outer, int64_t len, int64_t inner, size_t esize) {
     constexpr int RMAX = 64 / VW;      // at most 64 floats of column data per thread
     const int64_t items = cdiv(inner, (int64_t)VW);
-    const bool small = outer * len * inner * (int64_t)sizeof(E) <= (8LL << 20);
+    const bool small = outer * len * inner * (int64_t)esize <= (8LL << 20);
+    for (const int tx : {64, 16, 8, 4}) {
+        const bool wide_enough = tx == 4 ? (items <= 4 || small) : items > tx / 2;
+        const int64_t blocks = outer * cdiv(items, (int64_t)tx);
+        if (wide_enough && cdiv(len, (int64_t)(256 / tx)) <= RMAX && (small || blocks >= 512 || tx == 4)) return tx;
+    }
+    return 0;
+}
+
+// Rows split over workgroups (needs a workspace): chosen when the column blocks alone are too few
+// workgroups for the chip.  tx = 0: no split.
+struct SplitPlan {
+    int tx = 0, nsplit = 0;
+    int64_t nchunk = 0, groups = 0, rows_per_split = 0;
+    size_t count_bytes = 0, bytes = 0;     // workspace: u32 count[groups] (zero at launch), padded; float fin[groups][2][W], part[groups][nsplit][2][W]
+};
+constexpr int kMaxSplit = 256;
+
+template <int VW>
+SplitPlan split_plan(int64_t outer, int64_t len, int64_t inner, size_t esize) {
+    SplitPlan p;
+    if (reg_tx<VW>(outer, len, inner, esize) != 0) return p;
+    const int64_t items = cdiv(inner, (int64_t)VW);
+    int tx = 4;
+    for (const int t : {16, 8}) if (items > t / 2) { tx = t; break; }
+    const int64_t groups = outer * cdiv(items, (int64_t)tx);
+    int64_t target = tuning().softmax_split_wgs;
+    if (target < 0) return p;
+    if (target == 0) target = 1024;
+    const int64_t nsplit = std::min<int64_t>({(int64_t)kMaxSplit, cdiv(target, groups), len / 64});
+    if (nsplit < 2 || groups * nsplit > 0x7fffffffLL) return p;
+    p.tx = tx;
+    p.rows_per_split = cdiv(len, nsplit);
+    p.nsplit = (int)cdiv(len, p.rows_per_split);
+    p.nchunk = cdiv(items, (int64_t)tx);
+    p.groups = groups;
+    p.count_bytes = ((size_t)groups * 4 + 255) / 256 * 256;
+    p.bytes = p.count_bytes + (size_t)groups * (size_t)(1 + p.nsplit) * 2 * (size_t)(tx * VW) * sizeof(float);
+    return p;
+}
+
+template <typename E, int VW, bool PRO>
+int launch_cols(const E* in, E* out, int64_t outer, int64_t len, int64_t inner, const Prologue& pro, hipStream_t s,
+                void* ws, size_t ws_bytes) {
+    constexpr int RMAX = 64 / VW;
+    const int64_t items = cdiv(inner, (int64_t)VW);
     auto blocks = [&](int tx) { return outer * cdiv(items, (int64_t)tx); };
+    const int rtx = reg_tx<VW>(outer, len, inner, sizeof(E));
 #define MYFA_REG(TXV) \
-    if ((TXV == 4 ? (items <= 4 || small) : items > TXV / 2) && cdiv(len, (int64_t)(256 / TXV)) <= RMAX && (small || blocks(TXV) >= 512 || TXV == 4)) { \
+    if (rtx == TXV) { \
         const int64_t nchunk = cdiv(items, (int64_t)TXV); \
         const dim3 g((unsigned)blocks(TXV)), b(256); \
         if (cdiv(len, (int64_t)(256 / TXV)) <= RMAX / 4) launch_kernel((softmax_cols_reg<E, TXV, VW, RMAX / 4, PRO>), g, b, 0, s, in, out, len, inner, nchunk, pro); \
         else launch_kernel((softmax_cols_reg<E, TXV, VW, RMAX, PRO>), g, b, 0, s, in, out, len, inner, nchunk, pro); \
-        return; \
+        return MYFA_OK; \
     }
     MYFA_REG(64) MYFA_REG(16) MYFA_REG(8) MYFA_REG(4)
 #undef MYFA_REG
+    if (const SplitPlan p = split_plan<VW>(outer, len, inner, sizeof(E)); ws != nullptr && p.tx != 0 && ws_bytes >= p.bytes) {
+        if (const hipError_t e = hipMemsetAsync(ws, 0, p.count_bytes, s); e != hipSuccess)
+            return fail(MYFA_E_LAUNCH, "softmax: clearing the workspace: %s", hipGetErrorString(e));
+        unsigned* count = static_cast<unsigned*>(ws);
+        float* stats = reinterpret_cast<float*>(static_cast<char*>(ws) + p.count_bytes);
+        const dim3 g((unsigned)(p.groups * p.nsplit)), b(256);
+#define MYFA_SPLIT(TXV) \
+        if (p.tx == TXV) { \
+            launch_kernel((softmax_cols_stream<E, TXV, VW, 256, PRO, 1>), g, b, 0, s, in, out, len, inner, p.nchunk, pro, p.groups, p.nsplit, p.rows_per_split, count, stats); \
+            launch_kernel((softmax_cols_stream<E, TXV, VW, 256, PRO, 2>), g, b, 0, s, in, out, len, inner, p.nchunk, pro, p.groups, p.nsplit, p.rows_per_split, count, stats); \
+            return MYFA_OK; \
+        }
+        MYFA_SPLIT(16) MYFA_SPLIT(8) MYFA_SPLIT(4)
+#undef MYFA_SPLIT
+    }
     const bool big = len >= 2048;
     constexpr int BIG = VW == 8 ? 512 : 1024;      // (eight-element items need the registers of a smaller workgroup)
 #define MYFA_STREAM(TXV, LAST) \
     if (LAST || (items > TXV / 2 && blocks(TXV) >= 256)) { \
         const int64_t nchunk = cdiv(items, (int64_t)TXV); \
         const dim3 g((unsigned)blocks(TXV)); \
-        if (big) launch_kernel((softmax_cols_stream<E, TXV, VW, BIG, PRO>), g, dim3(BIG), 0, s, in, out, len, inner, nchunk, pro); \
-        else launch_kernel((softmax_cols_stream<E, TXV, VW, 256, PRO>), g, dim3(256), 0, s, in, out, len, inner, nchunk, pro); \
-        return; \
+        if (big) launch_kernel((softmax_cols_stream<E, TXV, VW, BIG, PRO>), g, dim3(BIG), 0, s, in, out, len, inner, nchunk, pro, (int64_t)0, 1, len, (unsigned*)nullptr, (float*)nullptr); \
+        else launch_kernel((softmax_cols_stream<E, TXV, VW, 256, PRO>), g, dim3(256), 0, s, in, out, len, inner, nchunk, pro, (int64_t)0, 1, len, (unsigned*)nullptr, (float*)nullptr); \
+        return MYFA_OK; \
     }
     MYFA_STREAM(64, false) MYFA_STREAM(16, false) MYFA_STREAM(8, items >= 8) MYFA_STREAM(4, true)
 #undef MYFA_STREAM
+    return MYFA_OK;
+}
+
+template <typename E>
+bool cols_vectorised(const E* in, const E* out, int64_t inner) {
+    return (inner % vec_width<E>() == 0) && (reinterpret_cast<uintptr_t>(in) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0);
 }
 
 template <typename E, bool PRO>
-int softmax_cols_any(const E* in, E* out, int64_t outer, int64_t len, int64_t inner, const Prologue& pro, hipStream_t s) {
+int softmax_cols_any(const E* in, E* out, int64_t outer, int64_t len, int64_t inner, const Prologue& pro, hipStream_t s,
+                     void* ws = nullptr, size_t ws_bytes = 0) {
     constexpr int VWV = vec_width<E>();
-    const bool vec = (inner % VWV == 0) && (reinterpret_cast<uintptr_t>(in) % 16 == 0) &&
-                     (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    const bool vec = cols_vectorised(in, out, inner);
     if (outer * cdiv(inner, (int64_t)(vec ? VWV : 1) * 4) > 0x7fffffffLL)
         return fail(MYFA_E_UNSUPPORTED, "softmax: outer=%lld x inner=%lld exceeds the grid limit", (long long)outer, (long long)inner);
-    if (vec) launch_cols<E, VWV, PRO>(in, out, outer, len, inner, pro, s);
-    else launch_cols<E, 1, PRO>(in, out, outer, len, inner, pro, s);
+    const int rc = vec ? launch_cols<E, VWV, PRO>(in, out, outer, len, inner, pro, s, ws, ws_bytes)
+                       : launch_cols<E, 1, PRO>(in, out, outer, len, inner, pro, s, nullptr, 0);   // (no workspace: no split)
+    if (rc != MYFA_OK) return rc;
     return check_launch("softmax_cols");
 }
 
@@ -273,8 +414,21 @@ int softmax_strided(const void* in, void* out, int64_t outer, int64_t len, int64
 // softmax(scale * x + mask) along `len`, optionally with the causal mask of square logits.
 //   mask: float32 [mask_outer, len, inner] or null; outer index o uses slice o % mask_outer
 //   causal: inner must be 1 and outer a multiple of len: row o is query o % len of a [.., len, len] tensor
+size_t softmax_strided_ws_bytes(int64_t outer, int64_t len, int64_t inner, int dtype) {
+    if (outer <= 0 || len <= 0 || inner <= 1) return 0;
+    switch (dtype) {
+        // (sized for 16-byte items; tensors that are not 16-byte aligned run element-wise and do not split)
+        case MYFA_F32:  return inner % 4 == 0 ? split_plan<4>(outer, len, inner, 4).bytes : 0;
+        case MYFA_F16:
+        case MYFA_BF16: return inner % 8 == 0 ? split_plan<8>(outer, len, inner, 2).bytes : 0;
+        default:        return 0;
+    }
+}
+
+// ws: null, or at least softmax_strided_ws_bytes() bytes, 16-byte aligned (a smaller one is ignored)
 int softmax_strided_pro(const void* in, void* out, int64_t outer, int64_t len, int64_t inner, int dtype,
-                        float scale, const float* mask, int64_t mask_outer, bool causal, hipStream_t s) {
+                        float scale, const float* mask, int64_t mask_outer, bool causal, hipStream_t s,
+                        void* ws, size_t ws_bytes) {
     bool empty;
     if (const int rc = check_sizes(in, out, outer, len, inner, dtype, empty); rc != MYFA_OK) return rc;
     if (mask != nullptr && (mask_outer < 1 || (!empty && outer % mask_outer != 0)))
@@ -290,9 +444,9 @@ int softmax_strided_pro(const void* in, void* out, int64_t outer, int64_t len, i
     pro.causal_rows = causal ? len : 0;
     if (inner == 1) return softmax_rows_pro(in, out, outer, len, dtype, pro, s);
     switch (dtype) {
-        case MYFA_F32:  return softmax_cols_any<float, true>(static_cast<const float*>(in), static_cast<float*>(out), outer, len, inner, pro, s);
-        case MYFA_F16:  return softmax_cols_any<_Float16, true>(static_cast<const _Float16*>(in), static_cast<_Float16*>(out), outer, len, inner, pro, s);
-        default:        return softmax_cols_any<__bf16, true>(static_cast<const __bf16*>(in), static_cast<__bf16*>(out), outer, len, inner, pro, s);
+        case MYFA_F32:  return softmax_cols_any<float, true>(static_cast<const float*>(in), static_cast<float*>(out), outer, len, inner, pro, s, ws, ws_bytes);
+        case MYFA_F16:  return softmax_cols_any<_Float16, true>(static_cast<const _Float16*>(in), static_cast<_Float16*>(out), outer, len, inner, pro, s, ws, ws_bytes);
+        default:        return softmax_cols_any<__bf16, true>(static_cast<const __bf16*>(in), static_cast<__bf16*>(out), outer, len, inner, pro, s, ws, ws_bytes);
     }
 }
 

@@ -28,6 +28,9 @@ struct Tuning {
     int attn_f32_wgs = 0;
     // row softmax launch shape override: threads per row, items per thread, map, nt, pad (tpr = 0: none)
     int softmax_shape[5] = {0, 0, 0, 3, 0};
+    // column softmax with the rows of a column block split over workgroups: workgroup count the split
+    // aims at (0 = the default, 1024; -1 = never split, as without a workspace)
+    int softmax_split_wgs = 0;
     // float32 matmul block edge: 0 = library's choice, 64 or 128
     int matmul_block = 0;
 };

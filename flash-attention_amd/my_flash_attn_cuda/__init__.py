@@ -153,7 +153,16 @@ def softmax(inp, dim=-1, scale=1.0, mask=None, causal=False):
     if causal and (dim != inp.dim() - 1 or inp.dim() < 2 or inp.shape[-1] != inp.shape[-2]):
         raise RuntimeError("causal=True needs dim to be the last dimension of (..., N, N) logits")
     with _on(inp):
-        if plain:
+        # long columns: with a workspace (torch's caching allocator, stream-ordered) the library splits
+        # the rows of a column block over workgroups and reads the tensor once instead of twice
+        nbytes = _lib.lib.myfa_softmax_nd_ws_bytes(outer, inp.shape[dim], inner, _DTYPE_TAG[inp.dtype])
+        if nbytes > 0:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=inp.device)
+            _lib.check(_lib.lib.myfa_softmax_nd_ws(inp.data_ptr(), out.data_ptr(), outer, inp.shape[dim], inner,
+                                                   _DTYPE_TAG[inp.dtype], float(scale),
+                                                   mask.data_ptr() if mask is not None else None, mask_outer,
+                                                   SOFTMAX_CAUSAL if causal else 0, ws.data_ptr(), nbytes, _stream()))
+        elif plain:
             _lib.check(_lib.lib.myfa_softmax_nd(inp.data_ptr(), out.data_ptr(), outer, inp.shape[dim], inner,
                                                 _DTYPE_TAG[inp.dtype], _stream()))
         else:

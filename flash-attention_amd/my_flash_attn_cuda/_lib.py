@@ -25,6 +25,8 @@ EXPORTS = (
     "myfa_softmax",
     "myfa_softmax_nd",
     "myfa_softmax_nd_ex",
+    "myfa_softmax_nd_ws_bytes",
+    "myfa_softmax_nd_ws",
     "myfa_attn_fwd_f32",
     "myfa_attn_fwd_f32_ws_bytes",
     "myfa_attn_fwd_f32_ws",
@@ -58,6 +60,10 @@ def _load():
     lib.myfa_softmax_nd.restype = ci
     lib.myfa_softmax_nd_ex.argtypes = [vp, vp, i64, i64, i64, ci, f32, vp, i64, ci, vp]
     lib.myfa_softmax_nd_ex.restype = ci
+    lib.myfa_softmax_nd_ws_bytes.argtypes = [i64, i64, i64, ci]
+    lib.myfa_softmax_nd_ws_bytes.restype = i64
+    lib.myfa_softmax_nd_ws.argtypes = [vp, vp, i64, i64, i64, ci, f32, vp, i64, ci, vp, i64, vp]
+    lib.myfa_softmax_nd_ws.restype = ci
     lib.myfa_attn_fwd_f32.argtypes = [vp, vp, vp, vp, i64, i64, f32, vp]
     lib.myfa_attn_fwd_f32.restype = ci
     lib.myfa_attn_fwd_f32_ws_bytes.argtypes = [i64, i64]

@@ -113,6 +113,27 @@ int myfa_softmax_nd_ex(const void* in, void* out, int64_t outer, int64_t len, in
                        float scale, const float* add_mask, int64_t mask_outer, int flags, void* stream);
 
 /*
+ * myfa_softmax_nd_ex with a caller workspace, for long columns (inner > 1 and more rows than one
+ * workgroup's registers hold, e.g. [8192, 8192] or [16384, 16384] along dimension 0): without a
+ * workspace such a column block is read twice (statistics, then values: 12 bytes per float32
+ * element); with one its rows are split over workgroups that hold their slices in registers and
+ * exchange (max, sum) pairs through the workspace: one read and one write (8 bytes per element).
+ * myfa_softmax_nd_ws_bytes(outer, len, inner, dtype) is the size that lets the library do so (0: the
+ * shape is not split -- rows, short columns, rows of fewer than eight 16-byte items, inner not a
+ * multiple of the 16-byte item, more than 256 slices; a smaller workspace, NULL, or tensors that
+ * are not 16-byte aligned fall back to what myfa_softmax_nd_ex does).  The library clears the part
+ * of the workspace it needs cleared on `stream` itself; the contents before and after the call
+ * mean nothing; it must stay untouched until the call's work on `stream` has finished, and two calls
+ * that may overlap need a workspace each.  Same result as myfa_softmax_nd_ex up to float32 rounding
+ * (exp(x - m_slice) * exp(m_slice - m) in place of exp(x - m)).  In-place is allowed.
+ * No counterpart in the reference (its softmax is one workgroup per row, csrc/my_flash_attn/softmax.cu:459-487).
+ */
+int64_t myfa_softmax_nd_ws_bytes(int64_t outer, int64_t len, int64_t inner, int dtype);
+int myfa_softmax_nd_ws(const void* in, void* out, int64_t outer, int64_t len, int64_t inner, int dtype,
+                       float scale, const float* add_mask, int64_t mask_outer, int flags,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
  * 2-D single-head attention, float32, the reference's calling convention:
  *     o = softmax(scale * (q @ k_t)) @ v
  * q: [n, d]; k_t: [d, n] (K already transposed, as the reference's caller

@@ -32,6 +32,9 @@ class Tuned:
         lib.myfa_attn_fwd_f32_ws_bytes.argtypes = [i64, i64]
         lib.myfa_attn_fwd_f32_ws_bytes.restype = i64
         lib.myfa_attn_fwd_f32_ws.argtypes = [vp, vp, vp, vp, i64, i64, f32, vp, i64, vp]
+        lib.myfa_softmax_nd_ws_bytes.argtypes = [i64, i64, i64, ci]
+        lib.myfa_softmax_nd_ws_bytes.restype = i64
+        lib.myfa_softmax_nd_ws.argtypes = [vp, vp, i64, i64, i64, ci, f32, vp, i64, ci, vp, i64, vp]
 
     def _check(self, rc):
         if rc != 0:
@@ -75,3 +78,15 @@ class Tuned:
         self._check(self.lib.myfa_softmax_f32(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1],
                                               torch.cuda.current_stream().cuda_stream))
         return out
+
+    def softmax_dim0(self, x, out=None, ws=None):
+        """softmax over dim 0 of a 2-D tensor; ws = a uint8 tensor to reuse, None = allocate what the library asks for.
+        Returns (out, ws)."""
+        out = torch.empty_like(x) if out is None else out
+        ln, inner = x.shape
+        nbytes = self.lib.myfa_softmax_nd_ws_bytes(1, ln, inner, _TAG[x.dtype])
+        if ws is None and nbytes > 0:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        self._check(self.lib.myfa_softmax_nd_ws(x.data_ptr(), out.data_ptr(), 1, ln, inner, _TAG[x.dtype], 1.0, None, 1, 0,
+                                                ws.data_ptr() if nbytes else None, nbytes, torch.cuda.current_stream().cuda_stream))
+        return out, (ws if nbytes else None)
