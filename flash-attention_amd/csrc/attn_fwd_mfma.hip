@@ -1,6 +1,7 @@
 // Fused attention forward for f16 / bf16 on gfx950 matrix cores.
 //
 //     O[b,h] = softmax(scale * Q[b,h] K[b,h]^T) V[b,h]      Q,K,V,O: [B,H,N,D], D in {64,128}
+// (head dims above 128: attn_fwd_mfma256.hip)
 //
 // This is the kernel the reference sketches and leaves as a TODO
 // (csrc/my_flash_attn/flash_attention.cu:23-69).  The math is the online-softmax
@@ -711,8 +712,10 @@ int launch(const void* q, const void* k, const void* v, void* o, float* lse,
 
 int attn_fwd_mfma16(const void* q, const void* k, const void* v, void* o, float* lse,
                     int64_t heads, int64_t N, int64_t d, float scale, float thr, int dtype, bool causal, hipStream_t s);
+int attn_fwd_mfma_wide(const void* q, const void* k, const void* v, void* o, float* lse,
+                       int64_t heads, int64_t N, int64_t d, float scale, float thr, int dtype, bool causal, hipStream_t s);
 
-// dtype: MYFA_F16 or MYFA_BF16; d: 64 or 128; heads = B*H
+// dtype: MYFA_F16 or MYFA_BF16; d: a multiple of 8 in 8..256; heads = B*H
 int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* lse,
                   int64_t heads, int64_t N, int64_t d, float scale, int dtype, bool causal, hipStream_t s) {
     if (!(scale > 0.f)) return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16): scale must be > 0, got %g", (double)scale);
@@ -721,6 +724,7 @@ int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* l
     // shape (random operands; measured +6..12 % at d = 128, +2 % at d = 64).  Under the causal mask
     // the 32x32x16 build is the faster one (its workgroups spend more of their time outside the
     // tile loop, and the mask costs the 16x16x32 build more).
+    if (d > 128) return attn_fwd_mfma_wide(q, k, v, o, lse, heads, N, d, scale, tuning().attn_thr, dtype, causal, s);
     const int variant = tuning().attn_variant;
     if (variant == 2 || (variant < 0 && !causal))
         return attn_fwd_mfma16(q, k, v, o, lse, heads, N, d, scale, tuning().attn_thr, dtype, causal, s);
@@ -732,7 +736,7 @@ int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* l
         if (dtype == MYFA_F16)  return big ? launch<_Float16, 128>(q, k, v, o, lse, heads, N, d, scale, causal, s)
                                            : launch<_Float16, 64>(q, k, v, o, lse, heads, N, d, scale, causal, s);
     }
-    return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16): head dim %lld is not a multiple of 8 in 8..128", (long long)d);
+    return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16): head dim %lld is not a multiple of 8 in 8..256", (long long)d);
 }
 
 }  // namespace myfa

@@ -213,9 +213,10 @@ def flash_attn_fwd(q, k, v, scale=1.0, return_lse=False, causal=False):
     or float32); k is NOT transposed.  scale defaults to 1.0, the reference's
     semantics (its tests compare against scaled_dot_product_attention(scale=1.0),
     tests/test_flash_attn.py:165,183); pass d ** -0.5 for the usual scaling.
-    float16/bfloat16 run on the matrix cores for every head dim that is a multiple of 8 up to 128
-    (64 and 128 at full speed, the others on the next build up with zero columns); other head dims
-    take a detour through padded or float32 copies (see below) and float32 takes any d <= 512.
+    float16/bfloat16 run on the matrix cores for every head dim that is a multiple of 8 up to 256
+    (64 and 128 at full speed, the others on the next build up -- 64, 128 or 256 columns -- with zero
+    columns); other head dims take a detour through padded or float32 copies (see below) and float32
+    takes any d <= 512.
     With return_lse=True also returns the float32 (B, H, N) row log-sum-exp of the
     scaled logits (the m + log l statistic of tests/test_flash_attn.py:58-59,98-99).
     causal=True masks key j for query i when j > i, as
@@ -232,12 +233,12 @@ def flash_attn_fwd(q, k, v, scale=1.0, return_lse=False, causal=False):
     if q.dtype not in _DTYPE_TAG:
         raise RuntimeError(f"unsupported dtype {q.dtype}")
     B, H, N, d = q.shape
-    if q.dtype != torch.float32 and d > 0 and (d % 8 != 0 or d > 128):
-        # Outside what the matrix-core kernels take (head dims that are multiples of 8 up to 128):
+    if q.dtype != torch.float32 and d > 0 and (d % 8 != 0 or d > 256):
+        # Outside what the matrix-core kernels take (head dims that are multiples of 8 up to 256):
         # pad the head dim with zero columns up to the next multiple of 8 (the logits do not change,
-        # the extra output columns are dropped), or, beyond 128, run the float32 kernel (any d <= 512)
+        # the extra output columns are dropped), or, beyond 256, run the float32 kernel (any d <= 512)
         # on widened copies.  Both cost extra passes over q, k, v; neither changes the result's dtype.
-        if d <= 128:
+        if d <= 256:
             pad = (-d) % 8
             qp, kp, vp = (torch.nn.functional.pad(t, (0, pad)) for t in (q, k, v))
             res = flash_attn_fwd(qp, kp, vp, scale=scale, return_lse=return_lse, causal=causal)

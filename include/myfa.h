@@ -175,7 +175,9 @@ int myfa_attn_fwd_f32_ws(const float* q, const float* k_t, const float* v, float
  * (out, Q, K, V, seq_len, d_head), host wrapper allocating out, l, m); its
  * math is the reference's Python Algorithm-1 restatement
  * (tests/test_flash_attn.py:46-101) applied per (batch, head).
- * MYFA_F16 / MYFA_BF16 run on MFMA and require d in {64, 128} and scale > 0; MYFA_F32 accepts
+ * MYFA_F16 / MYFA_BF16 run on MFMA and require d a multiple of 8 in 8..256 (64 and 128 are the fast
+ * builds; the others run on the next build up -- 64, 128 or 256 columns -- with the missing columns
+ * read as zeros), 16-byte aligned tensors and scale > 0; MYFA_F32 accepts
  * 1 <= d <= 512, B*H <= 65535 and N*d < 2^31 (myfa_attn_fwd_f32 has the same d and N*d limits;
  * the reference's my_attention has none, but its test shapes end at N = 1025, d = 99).  Outside
  * these limits the call returns MYFA_E_UNSUPPORTED.

@@ -240,6 +240,29 @@ def _sampled_check(mfa, c_oracle, B, H, N, d, dtype, scale, heads, nrows, seed=1
     return q, k, v, out, worst
 
 
+@pytest.mark.parametrize("dtype,d", [(torch.bfloat16, 256), (torch.float16, 192), (torch.bfloat16, 136)])
+def test_wide_head_dims_sampled(mfa, c_oracle, dtype, d):
+    """Head dims above 128 (the 256-column build, one wave per SIMD): B=2 H=8 N=2048, sampled rows
+    against all keys, unscaled (saturating) and scaled logits; rows past the last full query block."""
+    for scale, n in ((d ** -0.5, 2048), (0.25, 1000)):
+        *_, worst = _sampled_check(mfa, c_oracle, 2, 8, n, d, dtype, scale, heads=[(0, 0), (1, 7)], nrows=64)
+        assert worst <= LP_ATOL
+
+
+def test_wide_rescale_branch_is_forced(mfa):
+    """The deferred rescale of the 256-column build: keys that raise single rows' max by far more
+    than the threshold, late in the sweep."""
+    torch.manual_seed(1)
+    N, d = 640, 256
+    q, k, v = (torch.randn(1, 1, N, d) for _ in range(3))
+    for row, key in [(0, 130), (5, 639), (31, 64), (32, 65), (100, 300), (127, 575), (128, 1), (639, 638)]:
+        k[0, 0, key] = q[0, 0, row] * 3.0
+    qd, kd, vd = (x.cuda().to(torch.bfloat16) for x in (q, k, v))
+    out = mfa.flash_attn_fwd(qd, kd, vd, scale=0.5)
+    ref = ref_cpu.attention_bhnd(*(_rounded(x, torch.bfloat16) for x in (q, k, v)), scale=0.5)
+    assert _maxdiff(out.float().cpu().numpy(), ref) <= LP_ATOL
+
+
 def test_config3_f16_full_size(mfa, c_oracle):
     """The f16 benchmark configuration: B=8 H=16 N=1024 d=64."""
     for scale in (1.0, 64 ** -0.5):

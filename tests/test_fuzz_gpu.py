@@ -35,10 +35,11 @@ def _cases(seed, count, dims):
     return out
 
 
-# 64 and 128 are the native builds; 8..120 in steps of 8 run on them with zero columns; the
-# reference's own odd head dims (tests/test_flash_attn.py:155: 1, 2, 20, 63, 65, 99) and 256 go
-# through the host layer's padded / float32 detours
-@pytest.mark.parametrize("case", _cases(11, 24, [64, 128]) + _cases(15, 28, [8, 32, 40, 96, 104, 120, 256, 1, 2, 20, 63, 65, 99]))
+# 64, 128 and 256 are the native builds; the other multiples of 8 up to 256 run on them with zero
+# columns; the reference's own odd head dims (tests/test_flash_attn.py:155: 1, 2, 20, 63, 65, 99)
+# and those above 256 go through the host layer's padded / float32 detours
+@pytest.mark.parametrize("case", _cases(11, 24, [64, 128]) + _cases(15, 28, [8, 32, 40, 96, 104, 120, 256, 1, 2, 20, 63, 65, 99])
+                         + _cases(17, 24, [136, 160, 192, 200, 248, 256, 130, 257, 264]))
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_fuzz_forward_lowp(mfa, dtype, case):
     B, H, N, d, causal, scale, seed = case
