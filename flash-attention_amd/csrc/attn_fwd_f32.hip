@@ -61,12 +61,16 @@ template <int NB> constexpr int max_waves() { return NB <= 4 ? 16 : NB <= 8 ? 8 
 // my_attention layout) instead of [N, d].  VEC: d % 4 == 0 and all bases 16-byte aligned, so rows
 // are read and written as float4; otherwise element by element.
 // CAUSAL: key j is visible to query i only if j <= i (batched entry point only).
-// FAST (needs VEC, K as [N, d], d == 16 NB, a head below 2 GiB, NB <= 8): K and V rows come through
+// BUF = 1 (needs VEC, K as [N, d], d == 16 NB, a head below 2 GiB, NB <= 8): K and V rows come through
 // buffer loads -- rows past N read as zero by the bounds check, so the loop has no row clamp, no
 // column guard and no 64-bit address arithmetic (those were 16 exec-masked branches and ~150 of
 // the ~380 instructions of a tile).
+// BUF = 2 (K as [d, N] -- the reference's my_attention --, a head below 2 GiB, NB <= 8, any d): the
+// same for the transposed K, element by element: rows of K^T past d lie past the end of the buffer
+// and read as zero; keys past N read the next row's first keys, which the softmax masks; V columns
+// past d read the next key's first columns and only reach output columns that are not stored.
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-template <int NB, bool KT, bool VEC, bool CAUSAL = false, bool FAST = false>
+template <int NB, bool KT, bool VEC, bool CAUSAL = false, int BUF = 0>
 __global__ void __launch_bounds__(max_waves<NB>() * 64)
 attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
                     const float* __restrict__ Vg, float* __restrict__ Og, float* __restrict__ LSEg,
@@ -135,19 +139,27 @@ attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
     // (rows past N are masked in the softmax; the clamp only keeps the address valid)
     [[maybe_unused]] f32x4 kf[PREFETCH ? NB : 1];
     [[maybe_unused]] __amdgpu_buffer_rsrc_t krs, vrs;
-    [[maybe_unused]] int k_voff = 0, v_voff = 0;
-    if constexpr (FAST) {
+    [[maybe_unused]] int k_voff = 0, v_voff = 0, kt_voff[4] = {0, 0, 0, 0};
+    if constexpr (BUF != 0) {
         const unsigned head_bytes = (unsigned)N * (unsigned)d * 4u;
         krs = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, head_bytes, 0x00020000);
         vrs = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, head_bytes, 0x00020000);
         k_voff = (j * d + 4 * g) * 4;            // K[key0 + j][16 b + 4 g ..]: + 64 b, + key0 * d * 4
         v_voff = (g * d + 4 * j) * 4;            // V[key0 + 4 r + g][64 bb + 4 j ..]: + 256 bb, + (key0 + 4 r) * d * 4
+#pragma unroll
+        for (int t = 0; t < 4; ++t) kt_voff[t] = ((4 * g + t) * N + j) * 4;   // K^T[16 b + 4 g + t][key0 + j]: + (16 b N + key0) * 4
     }
     auto load_k = [&](int kt) __attribute__((always_inline)) {
-        if constexpr (FAST) {
+        if constexpr (BUF == 1) {
 #pragma unroll
             for (int b = 0; b < NB; ++b)
                 kf[b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, k_voff + 64 * b, kt * 16 * d * 4, 0));
+        } else if constexpr (BUF == 2) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    kf[b][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(krs, kt_voff[t], (16 * b * N + kt * 16) * 4, 0));
         } else {
             const int key = min(kt * 16 + j, N - 1);
 #pragma unroll
@@ -160,12 +172,20 @@ attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
         const int key0 = kt * 16;
         // ---- V of this tile is requested now and consumed after the logits
         [[maybe_unused]] f32x4 vf[PREFETCH ? 4 : 1][PREFETCH ? NBB : 1];
-        if constexpr (FAST) {
+        if constexpr (BUF == 1 || (BUF == 2 && VEC)) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int bb = 0; bb < NBB; ++bb)
                     vf[r][bb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, v_voff + 256 * bb, (key0 + 4 * r) * d * 4, 0));
+        } else if constexpr (BUF == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int bb = 0; bb < NBB; ++bb)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        vf[r][bb][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vrs, v_voff + 256 * bb + 4 * t, (key0 + 4 * r) * d * 4, 0));
         } else if constexpr (PREFETCH) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -191,7 +211,7 @@ attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
             c += c2;
             // K of this wave's next tile goes into the registers just consumed; its latency
             // is covered by the softmax and the P.V product below
-            load_k(FAST ? kt + KS : min(kt + KS, ntiles - 1));   // (FAST: a tile past the end reads zeros)
+            load_k(BUF != 0 ? kt + KS : min(kt + KS, ntiles - 1));   // (buffer loads: a tile past the end is harmless)
         } else {
             const int key = min(key0 + j, N - 1);
 #pragma unroll
@@ -350,9 +370,11 @@ int launch(const float* q, const float* k, const float* v, float* o, float* lse,
            int64_t heads, int64_t N, int64_t d, float scale, hipStream_t s,
            float* ws = nullptr, size_t ws_bytes = 0) {
     constexpr bool can_fast = VEC && !KT && NB <= 8;
-    const bool fast = can_fast && d == 16 * NB && N * d * 4 < (1LL << 31);
-    auto kern = attn_fwd_f32_kernel<NB, KT, VEC, CAUSAL, false>;
-    if constexpr (can_fast) { if (fast) kern = attn_fwd_f32_kernel<NB, KT, VEC, CAUSAL, true>; }
+    constexpr bool can_kt = KT && !CAUSAL && NB <= 8;
+    const bool small_head = N * d * 4 < (1LL << 31);
+    auto kern = attn_fwd_f32_kernel<NB, KT, VEC, CAUSAL, 0>;
+    if constexpr (can_fast) { if (small_head && d == 16 * NB) kern = attn_fwd_f32_kernel<NB, KT, VEC, CAUSAL, 1>; }
+    if constexpr (can_kt) { if (small_head) kern = attn_fwd_f32_kernel<NB, KT, VEC, CAUSAL, 2>; }
     constexpr int wmax = max_waves<NB>();
     const int64_t qgroups = cdiv(N, 16);
     const int64_t ntiles = cdiv(N, 16);

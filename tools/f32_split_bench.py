@@ -9,10 +9,10 @@ import torch
 
 t = Tuned()
 torch.manual_seed(1)
-for n, d in ((128, 64), (1024, 64), (1025, 65), (2048, 128)):
+for n, d in ((128, 64), (512, 64), (1024, 64), (1025, 65), (1025, 99), (2048, 128)):
     q, k, v = (torch.randn(n, d, device="cuda") for _ in range(3))
     kt = k.t().contiguous()
-    for label, kn, ws in (("no workspace", {}, False), ("256", {"attn_f32_wgs": 256}, True), ("512", {"attn_f32_wgs": 512}, True),
+    for label, kn, ws in (("no workspace", {}, False), ("256", {"attn_f32_wgs": 256}, True), ("320", {"attn_f32_wgs": 320}, True), ("384", {"attn_f32_wgs": 384}, True), ("512", {"attn_f32_wgs": 512}, True),
                           ("1024", {"attn_f32_wgs": 1024}, True), ("2048", {"attn_f32_wgs": 2048}, True)):
         t.set(**kn)
         for _ in range(5):
