@@ -12,7 +12,7 @@
 //
 // Two kernels in this file, both on v_mfma_f32_32x32x16 (the 16x16x32 build of the same design is
 // attn_fwd_mfma16.hip; the launcher at the bottom picks between them):
-//   attn_fwd_mfma_pp_kernel  the one that ships for the causal mask: K/V tiles fetched by LDS-DMA
+//   attn_fwd_mfma_pp_kernel  the first ping-pong build (only the tuning flavour can select it): K/V tiles fetched by LDS-DMA
 //                            (buffer_load ... lds) into rings of 4 / 3 slots, the two waves of a
 //                            SIMD in opposite phases (matrix / softmax), one s_barrier per phase.
 //                            Described in the comment in front of it.
@@ -720,13 +720,14 @@ int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* l
                   int64_t heads, int64_t N, int64_t d, float scale, int dtype, bool causal, hipStream_t s) {
     if (!(scale > 0.f)) return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16): scale must be > 0, got %g", (double)scale);
     if (N > 0x7fffffffLL / 256) return fail(MYFA_E_UNSUPPORTED, "attention: N=%lld too large", (long long)N);
-    // The 16x16x32 build is the default without a mask: the chip holds a higher clock on that MFMA
-    // shape (random operands; measured +6..12 % at d = 128, +2 % at d = 64).  Under the causal mask
-    // the 32x32x16 build is the faster one (its workgroups spend more of their time outside the
-    // tile loop, and the mask costs the 16x16x32 build more).
+    // The 16x16x32 build is the default: the chip holds a higher clock on that MFMA shape (random
+    // operands; measured +6..12 % at d = 128, +2 % at d = 64 without a mask).  Under the causal mask
+    // its tile loop is split in two, unmasked tiles in front of the workgroup's rows and the masked
+    // tiles on the diagonal, so the first loop is the unmasked kernel's code: even with the 32x32x16
+    // build at d = 128 (N = 4096; +1 % at N = 16384) and +32..38 % at d = 64.
     if (d > 128) return attn_fwd_mfma_wide(q, k, v, o, lse, heads, N, d, scale, tuning().attn_thr, dtype, causal, s);
     const int variant = tuning().attn_variant;
-    if (variant == 2 || (variant < 0 && !causal))
+    if (variant == 2 || variant < 0)
         return attn_fwd_mfma16(q, k, v, o, lse, heads, N, d, scale, tuning().attn_thr, dtype, causal, s);
     // head dims that are multiples of 8 run on the next build up, the missing columns read as zeros
     if (d >= 8 && d <= 128 && d % 8 == 0) {

@@ -257,10 +257,13 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
     };
     auto nothing = [](int) __attribute__((always_inline)) {};
 
-    auto softmax = [&](int kv0) __attribute__((always_inline)) {
+    // MASK = false: a tile that lies before every row of the workgroup and inside N (causal builds
+    // run those tiles in a loop of their own, whose code then is the code of the unmasked kernel)
+    auto softmax = [&](int kv0, auto mask_flag) __attribute__((always_inline)) {
+        constexpr bool MASK = decltype(mask_flag)::value != 0;
         // keys past N, and under the causal mask keys after the lane's query rows; a tile the
         // wave's first row already covers entirely needs no look
-        if (kv0 + kBKV16 > N || (CAUSAL && kv0 + kBKV16 - 1 > q0 + 32 * wave_u)) {
+        if (MASK && (kv0 + kBKV16 > N || (CAUSAL && kv0 + kBKV16 - 1 > q0 + 32 * wave_u))) {
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -389,7 +392,7 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
         }
     });
     if (grp) __syncthreads();
-    softmax(0);
+    softmax(0, IC<1>{});
     dma_wait();                              // K(2), V(1): every wave's share is in before the barrier
     prefill(1, 0, IC<0>{}, IC<NQ + NP>{});   // first fragments of M(0): K(1), complete since the prologue
     phase_barrier();
@@ -398,7 +401,7 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
     // fetches of K(t+3) and V(t+2) are issued under the last MFMAs of M(t), behind the phase's last
     // fragment request, and every wave waits for its own at the end of its X(t+1).
     int k1 = 1, v0 = 0;              // (t+1) % 4, t % 3
-    for (int t = 0; t + 1 < T_; ++t) {
+    auto tile_step = [&](int t, auto mask_flag) __attribute__((always_inline)) {
         const int k2 = (k1 + 1) & 3;             // (t+2) % 4
         const int k3 = (k1 + 2) & 3;             // (t+3) % 4
         const int v1 = v0 == 2 ? 0 : v0 + 1;     // (t+1) % 3
@@ -414,12 +417,19 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
         });
         phase_barrier();                         // the fetches just issued stay in flight across it
         // ---- X(t+1)
-        softmax((t + 1) * kBKV16);
+        softmax((t + 1) * kBKV16, mask_flag);
         dma_wait();                              // this wave's share of K(t+3), V(t+2) is in LDS
         prefill(k2, v1, IC<0>{}, IC<NQ + NP>{}); // first fragments of M(t+1): K(t+2)
         phase_barrier();
         k1 = k2; v0 = v1;
+    };
+    int t = 0;
+    if constexpr (CAUSAL) {
+        // tiles 1 .. t_clean-1 lie before the workgroup's first row and inside N: no mask code
+        const int t_clean = min(q0, N) / kBKV16;
+        for (; t + 1 < min(T_, t_clean); ++t) tile_step(t, IC<0>{});
     }
+    for (; t + 1 < T_; ++t) tile_step(t, IC<1>{});
     prefill(0, v0, IC<NQ>{}, IC<NQ + NP>{});
     mma_stream(0, v0, IC<NQ>{}, IC<NQ + NP>{}, nothing);   // M(T-1): O += V(T-1)^T P^T
     dma_wait();
