@@ -13,14 +13,49 @@
 //   softmax_rows_stream<VW>       longer rows: online (max, sum) pass, then a
 //                                 second pass that re-reads and writes (12 B/elt)
 // An item is 16 bytes: VW = 4 floats, or 8 halves / bfloat16s (the element type E is a
-// template parameter; arithmetic is float32 whatever E is).  That needs w % VW == 0 (then
-// every row base is 16-byte aligned given a 16-byte aligned tensor base); otherwise VW = 1.
+// template parameter; arithmetic is float32 whatever E is).  With w % VW == 0 every row base is
+// 16-byte aligned given a 16-byte aligned tensor base.  Otherwise (SHIFT) a row starts `a`
+// elements past a 16-byte boundary, a different `a` from row to row: its items are then the aligned
+// 16-byte groups that cover it, item i holding columns i*VW - a .. i*VW - a + VW - 1; only the
+// first and the last item of a row are partial, and those are read and written element by element
+// (nothing outside the row is touched).  VW = 1 is left for tensors whose base is not 16-byte aligned.
 #include "softmax_common.h"
 #include "tuning.h"
 
 
 namespace myfa {
 namespace {
+
+// One item of a row under SHIFT: columns col0 .. col0 + VW - 1, of which those outside 0 .. w-1 do
+// not belong to the row (they read as -inf and are not written).
+template <typename E, int VW, bool NT, bool PRO>
+__device__ __forceinline__ void load_item(float (&x)[VW], const E* src, int64_t col0, int64_t row, int64_t w, const Prologue& pro) {
+    if (col0 >= 0 && col0 + VW <= w) {
+        vload<E, VW, NT>(x, src + col0);
+        if constexpr (PRO) prologue_row<VW>(x, pro, row, w, col0);
+    } else {
+#pragma unroll
+        for (int c = 0; c < VW; ++c) {
+            const int64_t col = col0 + c;
+            x[c] = -INFINITY;
+            if (col >= 0 && col < w) {
+                float e[1] = {(float)src[col]};
+                if constexpr (PRO) prologue_row<1>(e, pro, row, w, col);
+                x[c] = e[0];
+            }
+        }
+    }
+}
+template <typename E, int VW, bool NT>
+__device__ __forceinline__ void store_item(E* dst, int64_t col0, int64_t w, const float (&x)[VW]) {
+    if (col0 >= 0 && col0 + VW <= w) {
+        vstore<E, VW, NT>(dst + col0, x);
+    } else {
+#pragma unroll
+        for (int c = 0; c < VW; ++c)
+            if (col0 + c >= 0 && col0 + c < w) dst[col0 + c] = (E)x[c];
+    }
+}
 
 // Combines one value per wave across the NW waves that share a row.
 // `slot` is this row's region of the LDS scratch (NW floats).
@@ -39,7 +74,7 @@ __device__ __forceinline__ float rowgroup_reduce(float wave_val, float* slot, in
     }
 }
 
-template <typename E, int TPR, int V, int VW, int NTM = 3, int MAP = 0, bool PRO = false>
+template <typename E, int TPR, int V, int VW, int NTM = 3, int MAP = 0, bool PRO = false, bool SHIFT = false>
 __global__ void __launch_bounds__((TPR < 256 ? 256 : TPR))
 softmax_rows_reg(const E* __restrict__ in, E* __restrict__ out, int64_t h, int64_t w, Prologue pro) {
     constexpr int BLOCK = TPR < 256 ? 256 : TPR;
@@ -65,14 +100,20 @@ softmax_rows_reg(const E* __restrict__ in, E* __restrict__ out, int64_t h, int64
         if constexpr (MAP == 0) return (int64_t)v * TPR + t;
         else return ((int64_t)(t >> 6) * V + v) * 64 + (t & 63);
     };
+    // SHIFT: the row starts `shift` elements past a 16-byte boundary; item i is columns i*VW - shift ..
+    const int shift = SHIFT ? (int)((row * w) % VW) : 0;
     float x[V][VW];
     float mx = -INFINITY;
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-        const int64_t col = item(v) * VW;
+        const int64_t col = item(v) * VW - shift;
         if (col < w) {
-            vload<E, VW, (NTM & 1) != 0>(x[v], src + col);
-            if constexpr (PRO) prologue_row<VW>(x[v], pro, row, w, col);
+            if constexpr (SHIFT) {
+                load_item<E, VW, (NTM & 1) != 0, PRO>(x[v], src, col, row, w, pro);
+            } else {
+                vload<E, VW, (NTM & 1) != 0>(x[v], src + col);
+                if constexpr (PRO) prologue_row<VW>(x[v], pro, row, w, col);
+            }
         } else {
 #pragma unroll
             for (int c = 0; c < VW; ++c) x[v][c] = -INFINITY;
@@ -97,17 +138,18 @@ softmax_rows_reg(const E* __restrict__ in, E* __restrict__ out, int64_t h, int64
     const float inv = 1.0f / sum;
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-        const int64_t col = item(v) * VW;
+        const int64_t col = item(v) * VW - shift;
         if (col < w) {
 #pragma unroll
             for (int c = 0; c < VW; ++c) x[v][c] *= inv;
-            vstore<E, VW, (NTM & 2) != 0>(dst + col, x[v]);
+            if constexpr (SHIFT) store_item<E, VW, (NTM & 2) != 0>(dst, col, w, x[v]);
+            else vstore<E, VW, (NTM & 2) != 0>(dst + col, x[v]);
         }
     }
 }
 
 // Rows too long to hold in registers: one 1024-thread workgroup per row.
-template <typename E, int VW, bool PRO = false>
+template <typename E, int VW, bool PRO = false, bool SHIFT = false>
 __global__ void __launch_bounds__(1024)
 softmax_rows_stream(const E* __restrict__ in, E* __restrict__ out, int64_t h, int64_t w, Prologue pro) {
     constexpr int T = 1024, NW = T / 64;
@@ -119,11 +161,16 @@ softmax_rows_stream(const E* __restrict__ in, E* __restrict__ out, int64_t h, in
     const int t = threadIdx.x, wave = t >> 6;
 
     // pass 1: per-thread online (max, sum of 2^((x - max) * log2e))
+    const int shift = SHIFT ? (int)((row * w) % VW) : 0;
     float mx = -INFINITY, sum = 0.f;
-    for (int64_t col = (int64_t)t * VW; col < w; col += (int64_t)T * VW) {
+    for (int64_t col = (int64_t)t * VW - shift; col < w; col += (int64_t)T * VW) {
         float x[VW];
-        vload<E, VW, false>(x, src + col);
-        if constexpr (PRO) prologue_row<VW>(x, pro, row, w, col);
+        if constexpr (SHIFT) {
+            load_item<E, VW, false, PRO>(x, src, col, row, w, pro);
+        } else {
+            vload<E, VW, false>(x, src + col);
+            if constexpr (PRO) prologue_row<VW>(x, pro, row, w, col);
+        }
         float cm = x[0];
 #pragma unroll
         for (int c = 1; c < VW; ++c) cm = fmaxf(cm, x[c]);
@@ -146,14 +193,19 @@ softmax_rows_stream(const E* __restrict__ in, E* __restrict__ out, int64_t h, in
     const float inv = 1.0f / row_sum;
 
     // pass 2: the row was just read, so most of it is still in L2 / Infinity Cache
-    for (int64_t col = (int64_t)t * VW; col < w; col += (int64_t)T * VW) {
+    for (int64_t col = (int64_t)t * VW - shift; col < w; col += (int64_t)T * VW) {
         float x[VW];
-        vload<E, VW>(x, src + col);
-        if constexpr (PRO) prologue_row<VW>(x, pro, row, w, col);
+        if constexpr (SHIFT) {
+            load_item<E, VW, true, PRO>(x, src, col, row, w, pro);
+        } else {
+            vload<E, VW>(x, src + col);
+            if constexpr (PRO) prologue_row<VW>(x, pro, row, w, col);
+        }
 #pragma unroll
         for (int c = 0; c < VW; ++c)
             x[c] = __builtin_amdgcn_exp2f((x[c] - row_mx) * kLog2e) * inv;
-        vstore<E, VW>(dst + col, x);
+        if constexpr (SHIFT) store_item<E, VW, true>(dst, col, w, x);
+        else vstore<E, VW>(dst + col, x);
     }
 }
 
@@ -163,12 +215,15 @@ softmax_rows_stream(const E* __restrict__ in, E* __restrict__ out, int64_t h, in
 //   pad : unused dynamic LDS, only there to cap the workgroups per CU
 struct Shape { int tpr, v, map, nt; unsigned pad; };
 
-template <typename E, int TPR, int V, int VW, bool PRO>
+template <typename E, int TPR, int V, int VW, bool PRO, bool SHIFT = false>
 void launch_reg(const E* in, E* out, int64_t h, int64_t w, hipStream_t s, const Shape& sh, const Prologue& pro) {
     constexpr int BLOCK = TPR < 256 ? 256 : TPR;
     constexpr int RPB = BLOCK / TPR;
     const dim3 g((unsigned)cdiv(h, RPB)), b(BLOCK);
-    if constexpr (PRO) {
+    if constexpr (SHIFT) {
+        // one load/store policy and item map for rows that are not 16-byte aligned (fewer builds)
+        launch_kernel((softmax_rows_reg<E, TPR, V, VW, 3, 0, PRO, true>), g, b, sh.pad, s, in, out, h, w, pro);
+    } else if constexpr (PRO) {
         // one load/store policy and item map for the fused-prologue flavour (fewer builds)
         launch_kernel((softmax_rows_reg<E, TPR, V, VW, 3, 0, true>), g, b, sh.pad, s, in, out, h, w, pro);
     } else if constexpr (VW > 1) {
@@ -181,10 +236,10 @@ void launch_reg(const E* in, E* out, int64_t h, int64_t w, hipStream_t s, const 
     }
 }
 
-template <typename E, int VW, bool PRO>
+template <typename E, int VW, bool PRO, bool SHIFT = false>
 bool dispatch_reg(const E* in, E* out, int64_t h, int64_t w, hipStream_t s, const Shape& sh, const Prologue& pro) {
 #define MYFA_CASE(T, VV) \
-    if (sh.tpr == T && sh.v == VV) { launch_reg<E, T, VV, VW, PRO>(in, out, h, w, s, sh, pro); return true; }
+    if (sh.tpr == T && sh.v == VV) { launch_reg<E, T, VV, VW, PRO, SHIFT>(in, out, h, w, s, sh, pro); return true; }
     MYFA_CASE(64, 1) MYFA_CASE(64, 2) MYFA_CASE(64, 4) MYFA_CASE(64, 8)
     MYFA_CASE(256, 1) MYFA_CASE(256, 2) MYFA_CASE(256, 4) MYFA_CASE(256, 8)
     MYFA_CASE(512, 2) MYFA_CASE(512, 4) MYFA_CASE(512, 8)
@@ -203,8 +258,21 @@ bool dispatch_reg(const E* in, E* out, int64_t h, int64_t w, hipStream_t s, cons
 // with non-temporal loads; stores are always non-temporal.
 // 16-bit elements put 8 values (8 registers) in an item, so they take the shapes with half the
 // items per thread wherever the float32 choice would exceed 64 registers of row data.
-Shape choose_shape(int64_t items, int64_t tensor_bytes, int vw) {
+Shape choose_shape(int64_t items, int64_t tensor_bytes, int vw, bool shifted = false) {
     Shape sh{0, 0, 0, tensor_bytes <= (128LL << 20) ? 2 : 3, 0};
+    if (shifted) {
+        // rows off the 16-byte grid come in every width: the smallest shape that holds the row
+        // (the measured exceptions below belong to the power-of-two widths they were measured at)
+        if (items <= 64)        { sh.tpr = 64;   sh.v = 1; }
+        else if (items <= 128)  { sh.tpr = 64;   sh.v = 2; }
+        else if (items <= 256)  { sh.tpr = 64;   sh.v = 4; }
+        else if (items <= 512)  { if (vw == 8) { sh.tpr = 256; sh.v = 2; } else { sh.tpr = 64; sh.v = 8; } }
+        else if (items <= 1024) { sh.tpr = 512;  sh.v = 2; }
+        else if (items <= 2048) { sh.tpr = 1024; sh.v = 2; }
+        else if (items <= 4096) { sh.tpr = 1024; sh.v = 4; }
+        else if (items <= 8192) { sh.tpr = 1024; sh.v = 8; }
+        return sh;
+    }
     if (vw == 8) {
         if (items <= 64)        { sh.tpr = 64;   sh.v = 1; }
         else if (items <= 128)  { sh.tpr = 64;   sh.v = 2; }
@@ -234,18 +302,23 @@ int softmax_any(const E* in, E* out, int64_t h, int64_t w, const Prologue& pro, 
     if (!in || !out) return fail(MYFA_E_INVALID, "softmax: null pointer");
     if (h > 0x7fffffffLL) return fail(MYFA_E_UNSUPPORTED, "softmax: h=%lld exceeds the grid limit", (long long)h);
     constexpr int VWV = vec_width<E>();
-    const bool vec = (w % VWV == 0) && (reinterpret_cast<uintptr_t>(in) % 16 == 0) &&
-                     (reinterpret_cast<uintptr_t>(out) % 16 == 0);
-    const int vw = vec ? VWV : 1;
-    Shape sh = choose_shape(w / vw, h * w * (int64_t)sizeof(E), vw);
+    const bool aligned = (reinterpret_cast<uintptr_t>(in) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+    const bool vec = aligned && (w % VWV == 0);
+    // rows that start off a 16-byte boundary: the aligned groups that cover a row, up to one more than w / VW
+    const bool shifted = aligned && !vec && w >= 2 * VWV;
+    const int vw = (vec || shifted) ? VWV : 1;
+    Shape sh = choose_shape(shifted ? cdiv(w + VWV - 1, (int64_t)VWV) : w / vw, h * w * (int64_t)sizeof(E), vw, shifted);
     // the tuning flavour of the library can force a launch shape (benchmark sweeps only)
     if (const int* f = tuning().softmax_shape; f[0] > 0 && (int64_t)f[0] * f[1] * vw >= w)
         sh = Shape{f[0], f[1], f[2], f[3], (unsigned)f[4]};
     bool done = false;
-    if (sh.tpr) done = vec ? dispatch_reg<E, VWV, PRO>(in, out, h, w, s, sh, pro) : dispatch_reg<E, 1, PRO>(in, out, h, w, s, sh, pro);
+    if (sh.tpr) done = vec ? dispatch_reg<E, VWV, PRO>(in, out, h, w, s, sh, pro)
+                   : shifted ? dispatch_reg<E, VWV, PRO, true>(in, out, h, w, s, sh, pro)
+                             : dispatch_reg<E, 1, PRO>(in, out, h, w, s, sh, pro);
     if (!done) {
-        if (vec) launch_kernel((softmax_rows_stream<E, VWV, PRO>), dim3((unsigned)h), dim3(1024), 0, s, in, out, h, w, pro);
-        else     launch_kernel((softmax_rows_stream<E, 1, PRO>), dim3((unsigned)h), dim3(1024), 0, s, in, out, h, w, pro);
+        if (vec)          launch_kernel((softmax_rows_stream<E, VWV, PRO>), dim3((unsigned)h), dim3(1024), 0, s, in, out, h, w, pro);
+        else if (shifted) launch_kernel((softmax_rows_stream<E, VWV, PRO, true>), dim3((unsigned)h), dim3(1024), 0, s, in, out, h, w, pro);
+        else              launch_kernel((softmax_rows_stream<E, 1, PRO>), dim3((unsigned)h), dim3(1024), 0, s, in, out, h, w, pro);
     }
     return check_launch("softmax_rows");
 }

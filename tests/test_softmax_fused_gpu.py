@@ -56,6 +56,7 @@ def _mask(shape, seed, frac=0.25):
 CASES = [
     ((3, 200, 200), -1, (200, 200), False), ((2, 2, 129, 129), -1, None, True), ((2, 515, 515), -1, (515, 515), True),
     ((4, 4096), -1, (4096,), False), ((2, 40000), -1, (2, 40000), False), ((3, 10001), -1, (10001,), False),
+    ((3, 40003), -1, (40003,), False), ((5, 1023, 1023), -1, None, True),
     ((2, 1024, 1024), -1, (1024, 1024), True), ((4, 100, 64), 1, (100, 64), False), ((2, 4, 300, 20), 2, (4, 300, 20), False),
     ((2, 2050, 1024), 1, (2050, 1024), False), ((4096, 512), 0, (4096, 512), False), ((1500, 97), 0, (1500, 97), False),
 ]

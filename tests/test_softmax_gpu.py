@@ -169,3 +169,42 @@ def test_lowp_errors(mfa):
         mfa.softmax_rows(torch.zeros(2, 2, dtype=torch.float64, device="cuda"))
     with pytest.raises(RuntimeError, match="2-D"):
         mfa.softmax_rows(torch.zeros(2, 2, 2, dtype=torch.bfloat16, device="cuda"))
+
+
+# rows that do not start on a 16-byte boundary (w not a multiple of 4 floats / 8 halves) are read as
+# the aligned 16-byte groups that cover them, first and last group element by element; every
+# launch class of that path, the streamed one (w > 32768) included, and its edges
+UNALIGNED = [(7, 9), (5, 33), (64, 255), (33, 257), (100, 1023), (9, 1025), (6, 2049), (5, 4097), (3, 8191),
+             (3, 12345), (2, 32767), (3, 40001), (2, 70003)]
+
+
+@pytest.mark.parametrize("shape", UNALIGNED)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_unaligned_rows_vs_oracle(mfa, shape, dtype):
+    from oracle import ref_cpu
+    torch.manual_seed(21)
+    h, w = shape
+    x = (torch.randn(h, w) * 3).to(dtype)
+    x[0, : min(w - 2, 5000)] = float("-inf")          # leading -inf (left padding) in the first row
+    guard = torch.full((h * w + 64,), 7.0, dtype=dtype, device="cuda")   # the output sits inside a guarded buffer
+    out = guard[32:32 + h * w].view(h, w)
+    xd = torch.empty(h * w + 64, dtype=dtype, device="cuda")[32:32 + h * w].view(h, w)
+    xd.copy_(x)
+    from my_flash_attn_cuda import _lib
+    tag = {torch.float32: _lib.MYFA_F32, torch.float16: _lib.MYFA_F16, torch.bfloat16: _lib.MYFA_BF16}[dtype]
+    rc = _lib.lib.myfa_softmax(xd.data_ptr(), out.data_ptr(), h, w, tag, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rc == 0
+    ref = ref_cpu.softmax_dim(x.float().numpy(), 1)
+    tol = {torch.float32: 0.0, torch.float16: 2.0 ** -11, torch.bfloat16: 2.0 ** -8}[dtype]
+    assert (np.abs(out.float().cpu().numpy() - ref) <= tol * ref + 1e-5).all()
+    # nothing outside the rows was written
+    assert bool((guard[:32] == 7.0).all()) and bool((guard[32 + h * w:] == 7.0).all())
+    # the same values as the element-wise path (tensor base off the 16-byte grid)
+    off = torch.empty(h * w + 64, dtype=dtype, device="cuda")
+    xo, oo = off[1:1 + h * w].view(h, w), torch.empty(h * w + 64, dtype=dtype, device="cuda")[1:1 + h * w].view(h, w)
+    xo.copy_(x)
+    rc = _lib.lib.myfa_softmax(xo.data_ptr(), oo.data_ptr(), h, w, tag, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rc == 0
+    assert float((oo.float() - out.float()).abs().max()) <= (1e-6 if dtype == torch.float32 else 2e-3)
