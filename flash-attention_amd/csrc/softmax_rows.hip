@@ -19,6 +19,7 @@
 // 16-byte groups that cover it, item i holding columns i*VW - a .. i*VW - a + VW - 1; only the
 // first and the last item of a row are partial, and those are read and written element by element
 // (nothing outside the row is touched).  VW = 1 is left for tensors whose base is not 16-byte aligned.
+#include <algorithm>
 #include "softmax_common.h"
 #include "tuning.h"
 
@@ -148,52 +149,98 @@ softmax_rows_reg(const E* __restrict__ in, E* __restrict__ out, int64_t h, int64
     }
 }
 
-// Rows too long to hold in registers: one 1024-thread workgroup per row.
-template <typename E, int VW, bool PRO = false, bool SHIFT = false>
+__device__ __forceinline__ void put(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float get(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Rows too long to hold in registers: 1024-thread workgroups.
+//   PHASE 0: one workgroup per row does both passes (grid = h).
+// With a workspace, few long rows (h far below the CU count) are also split into `nsplit` slices
+// of `ips` items, one workgroup each, in two launches (grid = h * nsplit, a row's slices adjacent):
+//   PHASE 1: (max, sum) of the slice -> part[row][slice][2]; the workgroup of a row that finishes
+//            last (a counter per row, zero at launch) merges the row's pairs into fin[row][2].
+//            Nobody waits for anybody.  The pairs cross workgroups inside the launch, so they are
+//            written and read with device-scope accesses (past the per-XCD L2s).
+//   PHASE 2: re-reads its slice and writes, with the row's (max, sum) from fin.
+// stats: float fin[h][2], then part[h][nsplit][2].
+template <typename E, int VW, bool PRO = false, bool SHIFT = false, int PHASE = 0>
 __global__ void __launch_bounds__(1024)
-softmax_rows_stream(const E* __restrict__ in, E* __restrict__ out, int64_t h, int64_t w, Prologue pro) {
+softmax_rows_stream(const E* __restrict__ in, E* __restrict__ out, int64_t h, int64_t w, Prologue pro,
+                    int nsplit, int64_t ips, unsigned* __restrict__ count, float* __restrict__ stats) {
     constexpr int T = 1024, NW = T / 64;
     __shared__ float scratch[NW];
-    const int64_t row = blockIdx.x;
+    const int64_t row = PHASE == 0 ? blockIdx.x : blockIdx.x / nsplit;
+    const int split = PHASE == 0 ? 0 : (int)(blockIdx.x % nsplit);
     if (row >= h) return;
     const E* src = in + row * w;
     E* dst = out + row * w;
     const int t = threadIdx.x, wave = t >> 6;
-
-    // pass 1: per-thread online (max, sum of 2^((x - max) * log2e))
+    // item i is columns i*VW - shift .. (SHIFT: the row starts `shift` elements past a 16-byte boundary)
     const int shift = SHIFT ? (int)((row * w) % VW) : 0;
-    float mx = -INFINITY, sum = 0.f;
-    for (int64_t col = (int64_t)t * VW - shift; col < w; col += (int64_t)T * VW) {
-        float x[VW];
-        if constexpr (SHIFT) {
-            load_item<E, VW, false, PRO>(x, src, col, row, w, pro);
-        } else {
-            vload<E, VW, false>(x, src + col);
-            if constexpr (PRO) prologue_row<VW>(x, pro, row, w, col);
-        }
-        float cm = x[0];
+    const int64_t col_begin = PHASE == 0 ? -(int64_t)shift : (int64_t)split * ips * VW - shift;
+    const int64_t col_end = PHASE == 0 ? w : (col_begin + ips * VW < w ? col_begin + ips * VW : w);
+
+    float row_mx, inv;
+    if constexpr (PHASE != 2) {
+        // pass 1: per-thread online (max, sum of 2^((x - max) * log2e))
+        float mx = -INFINITY, sum = 0.f;
+        for (int64_t col = col_begin + (int64_t)t * VW; col < col_end; col += (int64_t)T * VW) {
+            float x[VW];
+            if constexpr (SHIFT) {
+                load_item<E, VW, false, PRO>(x, src, col, row, w, pro);
+            } else {
+                vload<E, VW, false>(x, src + col);
+                if constexpr (PRO) prologue_row<VW>(x, pro, row, w, col);
+            }
+            float cm = x[0];
 #pragma unroll
-        for (int c = 1; c < VW; ++c) cm = fmaxf(cm, x[c]);
-        if (cm > mx) {
-            sum *= __builtin_amdgcn_exp2f((mx - cm) * kLog2e);  // mx = -inf first time: sum is 0
-            mx = cm;
-        }
-        // while everything this thread has seen is -inf there is nothing to add: (-inf) - (-inf) is
-        // NaN, and a NaN in `sum` would survive the later rescale by 0 (leading -inf elements of a
-        // row are ordinary input: left padding, sliding-window masks)
-        if (mx != -INFINITY) {
+            for (int c = 1; c < VW; ++c) cm = fmaxf(cm, x[c]);
+            if (cm > mx) {
+                sum *= __builtin_amdgcn_exp2f((mx - cm) * kLog2e);  // mx = -inf first time: sum is 0
+                mx = cm;
+            }
+            // while everything this thread has seen is -inf there is nothing to add: (-inf) - (-inf) is
+            // NaN, and a NaN in `sum` would survive the later rescale by 0 (leading -inf elements of a
+            // row are ordinary input: left padding, sliding-window masks)
+            if (mx != -INFINITY) {
 #pragma unroll
-            for (int c = 0; c < VW; ++c) sum += __builtin_amdgcn_exp2f((x[c] - mx) * kLog2e);
+                for (int c = 0; c < VW; ++c) sum += __builtin_amdgcn_exp2f((x[c] - mx) * kLog2e);
+            }
         }
+        row_mx = rowgroup_reduce<NW>(wave_max(mx), scratch, wave, MaxOp{});
+        // threads that saw no element have mx = -inf, sum = 0: contribute 0
+        const float part = (mx == -INFINITY) ? 0.f : sum * __builtin_amdgcn_exp2f((mx - row_mx) * kLog2e);
+        const float row_sum = rowgroup_reduce<NW>(wave_sum(part), scratch, wave, SumOp{});
+        inv = 1.0f / row_sum;
+
+        if constexpr (PHASE == 1) {
+            float* fin = stats + row * 2;
+            float* parts = stats + (h + row * nsplit) * 2;
+            __shared__ unsigned s_last;
+            if (t == 0) {
+                put(parts + 2 * split, row_mx);
+                put(parts + 2 * split + 1, row_sum);
+            }
+            __syncthreads();       // (waits for the stores above to have completed)
+            if (t == 0)
+                s_last = __hip_atomic_fetch_add(count + row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nsplit - 1);
+            __syncthreads();
+            if (!s_last) return;   // uniform over the workgroup
+            // at most 1024 slices: one pair per thread
+            const float pm = t < nsplit ? get(parts + 2 * t) : -INFINITY;
+            const float pl = t < nsplit ? get(parts + 2 * t + 1) : 0.f;
+            const float M = rowgroup_reduce<NW>(wave_max(pm), scratch, wave, MaxOp{});
+            const float pls = (pm == -INFINITY) ? 0.f : pl * __builtin_amdgcn_exp2f((pm - M) * kLog2e);
+            const float S = rowgroup_reduce<NW>(wave_sum(pls), scratch, wave, SumOp{});
+            if (t == 0) { fin[0] = M; fin[1] = S; }
+            return;
+        }
+    } else {
+        row_mx = stats[row * 2];
+        inv = 1.0f / stats[row * 2 + 1];
     }
-    const float row_mx = rowgroup_reduce<NW>(wave_max(mx), scratch, wave, MaxOp{});
-    // threads that saw no element have mx = -inf, sum = 0: contribute 0
-    const float part = (mx == -INFINITY) ? 0.f : sum * __builtin_amdgcn_exp2f((mx - row_mx) * kLog2e);
-    const float row_sum = rowgroup_reduce<NW>(wave_sum(part), scratch, wave, SumOp{});
-    const float inv = 1.0f / row_sum;
 
     // pass 2: the row was just read, so most of it is still in L2 / Infinity Cache
-    for (int64_t col = (int64_t)t * VW - shift; col < w; col += (int64_t)T * VW) {
+    for (int64_t col = col_begin + (int64_t)t * VW; col < col_end; col += (int64_t)T * VW) {
         float x[VW];
         if constexpr (SHIFT) {
             load_item<E, VW, true, PRO>(x, src, col, row, w, pro);
@@ -295,8 +342,28 @@ Shape choose_shape(int64_t items, int64_t tensor_bytes, int vw, bool shifted = f
     return sh;
 }
 
+// Few long rows with a workspace: slices of a row over workgroups.  nsplit = 0: no split.
+struct RowSplit {
+    int nsplit = 0;
+    int64_t ips = 0;                       // items per slice, a multiple of the 1024 threads
+    size_t count_bytes = 0, bytes = 0;     // workspace: u32 count[h] (zero at launch), padded; float fin[h][2], part[h][nsplit][2]
+};
+// items: 16-byte items per row (covering groups for rows off the 16-byte grid)
+RowSplit rows_split_plan(int64_t h, int64_t items) {
+    RowSplit p;
+    if (items <= 8192 || h >= 256) return p;          // the register-resident kernel, or rows enough for the chip
+    const int64_t nsplit = std::min<int64_t>({1024, cdiv((int64_t)1024, h), items / 2048});
+    if (nsplit < 2) return p;
+    p.ips = cdiv(cdiv(items, nsplit), (int64_t)1024) * 1024;
+    p.nsplit = (int)cdiv(items, p.ips);
+    p.count_bytes = ((size_t)h * 4 + 255) / 256 * 256;
+    p.bytes = p.count_bytes + (size_t)h * (size_t)(1 + p.nsplit) * 2 * sizeof(float);
+    return p;
+}
+
 template <typename E, bool PRO>
-int softmax_any(const E* in, E* out, int64_t h, int64_t w, const Prologue& pro, hipStream_t s) {
+int softmax_any(const E* in, E* out, int64_t h, int64_t w, const Prologue& pro, hipStream_t s,
+                void* ws = nullptr, size_t ws_bytes = 0) {
     if (h < 0 || w < 0) return fail(MYFA_E_INVALID, "softmax: negative size h=%lld w=%lld", (long long)h, (long long)w);
     if (h == 0 || w == 0) return MYFA_OK;
     if (!in || !out) return fail(MYFA_E_INVALID, "softmax: null pointer");
@@ -316,9 +383,23 @@ int softmax_any(const E* in, E* out, int64_t h, int64_t w, const Prologue& pro, 
                    : shifted ? dispatch_reg<E, VWV, PRO, true>(in, out, h, w, s, sh, pro)
                              : dispatch_reg<E, 1, PRO>(in, out, h, w, s, sh, pro);
     if (!done) {
-        if (vec)          launch_kernel((softmax_rows_stream<E, VWV, PRO>), dim3((unsigned)h), dim3(1024), 0, s, in, out, h, w, pro);
-        else if (shifted) launch_kernel((softmax_rows_stream<E, VWV, PRO, true>), dim3((unsigned)h), dim3(1024), 0, s, in, out, h, w, pro);
-        else              launch_kernel((softmax_rows_stream<E, 1, PRO>), dim3((unsigned)h), dim3(1024), 0, s, in, out, h, w, pro);
+        const RowSplit p = (vec || shifted) ? rows_split_plan(h, shifted ? cdiv(w + VWV - 1, (int64_t)VWV) : w / VWV) : RowSplit{};
+        if (ws != nullptr && p.nsplit > 1 && ws_bytes >= p.bytes) {
+            if (const hipError_t e = hipMemsetAsync(ws, 0, p.count_bytes, s); e != hipSuccess)
+                return fail(MYFA_E_LAUNCH, "softmax: clearing the workspace: %s", hipGetErrorString(e));
+            unsigned* count = static_cast<unsigned*>(ws);
+            float* stats = reinterpret_cast<float*>(static_cast<char*>(ws) + p.count_bytes);
+            const dim3 g((unsigned)(h * p.nsplit)), b(1024);
+            if (vec) {
+                launch_kernel((softmax_rows_stream<E, VWV, PRO, false, 1>), g, b, 0, s, in, out, h, w, pro, p.nsplit, p.ips, count, stats);
+                launch_kernel((softmax_rows_stream<E, VWV, PRO, false, 2>), g, b, 0, s, in, out, h, w, pro, p.nsplit, p.ips, count, stats);
+            } else {
+                launch_kernel((softmax_rows_stream<E, VWV, PRO, true, 1>), g, b, 0, s, in, out, h, w, pro, p.nsplit, p.ips, count, stats);
+                launch_kernel((softmax_rows_stream<E, VWV, PRO, true, 2>), g, b, 0, s, in, out, h, w, pro, p.nsplit, p.ips, count, stats);
+            }
+        } else if (vec)   launch_kernel((softmax_rows_stream<E, VWV, PRO>), dim3((unsigned)h), dim3(1024), 0, s, in, out, h, w, pro, 1, (int64_t)0, (unsigned*)nullptr, (float*)nullptr);
+        else if (shifted) launch_kernel((softmax_rows_stream<E, VWV, PRO, true>), dim3((unsigned)h), dim3(1024), 0, s, in, out, h, w, pro, 1, (int64_t)0, (unsigned*)nullptr, (float*)nullptr);
+        else              launch_kernel((softmax_rows_stream<E, 1, PRO>), dim3((unsigned)h), dim3(1024), 0, s, in, out, h, w, pro, 1, (int64_t)0, (unsigned*)nullptr, (float*)nullptr);
     }
     return check_launch("softmax_rows");
 }
@@ -341,13 +422,24 @@ int softmax_rows(const void* in, void* out, int64_t h, int64_t w, int dtype, hip
 
 // The same with the fused prologue (scale, additive mask, causal rows); pro.mask / pro.causal_rows
 // are indexed by the row number, so h is the `outer` of the [outer, len] view.
-int softmax_rows_pro(const void* in, void* out, int64_t h, int64_t w, int dtype, const Prologue& pro, hipStream_t s) {
+// ws: null, or at least softmax_rows_ws_bytes() bytes, 16-byte aligned (a smaller one is ignored)
+int softmax_rows_pro(const void* in, void* out, int64_t h, int64_t w, int dtype, const Prologue& pro, hipStream_t s,
+                     void* ws, size_t ws_bytes) {
     switch (dtype) {
-        case MYFA_F32:  return softmax_any<float, true>(static_cast<const float*>(in), static_cast<float*>(out), h, w, pro, s);
-        case MYFA_F16:  return softmax_any<_Float16, true>(static_cast<const _Float16*>(in), static_cast<_Float16*>(out), h, w, pro, s);
-        case MYFA_BF16: return softmax_any<__bf16, true>(static_cast<const __bf16*>(in), static_cast<__bf16*>(out), h, w, pro, s);
+        case MYFA_F32:  return softmax_any<float, true>(static_cast<const float*>(in), static_cast<float*>(out), h, w, pro, s, ws, ws_bytes);
+        case MYFA_F16:  return softmax_any<_Float16, true>(static_cast<const _Float16*>(in), static_cast<_Float16*>(out), h, w, pro, s, ws, ws_bytes);
+        case MYFA_BF16: return softmax_any<__bf16, true>(static_cast<const __bf16*>(in), static_cast<__bf16*>(out), h, w, pro, s, ws, ws_bytes);
         default:        return fail(MYFA_E_INVALID, "softmax: unknown dtype tag %d", dtype);
     }
+}
+
+// Workspace with which few long rows are split over workgroups; 0: they are not (short rows, rows
+// enough for the chip).  Sized for 16-byte aligned tensors (others run element-wise, unsplit).
+size_t softmax_rows_ws_bytes(int64_t h, int64_t w, int dtype) {
+    if (h <= 0 || w <= 0) return 0;
+    const int64_t vw = dtype == MYFA_F32 ? 4 : (dtype == MYFA_F16 || dtype == MYFA_BF16) ? 8 : 0;
+    if (vw == 0) return 0;
+    return rows_split_plan(h, w % vw == 0 ? w / vw : cdiv(w + vw - 1, vw)).bytes;
 }
 
 }  // namespace myfa

@@ -19,7 +19,9 @@
 
 namespace myfa {
 int softmax_rows(const void* in, void* out, int64_t h, int64_t w, int dtype, hipStream_t s);
-int softmax_rows_pro(const void* in, void* out, int64_t h, int64_t w, int dtype, const Prologue& pro, hipStream_t s);
+int softmax_rows_pro(const void* in, void* out, int64_t h, int64_t w, int dtype, const Prologue& pro, hipStream_t s,
+                     void* ws, size_t ws_bytes);
+size_t softmax_rows_ws_bytes(int64_t h, int64_t w, int dtype);
 namespace {
 
 // Column statistics across the TY threads of a column: red is [TY][TX * VW] floats.
@@ -415,7 +417,8 @@ int softmax_strided(const void* in, void* out, int64_t outer, int64_t len, int64
 //   mask: float32 [mask_outer, len, inner] or null; outer index o uses slice o % mask_outer
 //   causal: inner must be 1 and outer a multiple of len: row o is query o % len of a [.., len, len] tensor
 size_t softmax_strided_ws_bytes(int64_t outer, int64_t len, int64_t inner, int dtype) {
-    if (outer <= 0 || len <= 0 || inner <= 1) return 0;
+    if (outer <= 0 || len <= 0 || inner <= 0) return 0;
+    if (inner == 1) return softmax_rows_ws_bytes(outer, len, dtype);
     switch (dtype) {
         // (sized for 16-byte items; tensors that are not 16-byte aligned run element-wise and do not split)
         case MYFA_F32:  return inner % 4 == 0 ? split_plan<4>(outer, len, inner, 4).bytes : 0;
@@ -442,7 +445,7 @@ int softmax_strided_pro(const void* in, void* out, int64_t outer, int64_t len, i
     pro.mask = mask;
     pro.mask_outer = mask != nullptr ? mask_outer : 1;
     pro.causal_rows = causal ? len : 0;
-    if (inner == 1) return softmax_rows_pro(in, out, outer, len, dtype, pro, s);
+    if (inner == 1) return softmax_rows_pro(in, out, outer, len, dtype, pro, s, ws, ws_bytes);
     switch (dtype) {
         case MYFA_F32:  return softmax_cols_any<float, true>(static_cast<const float*>(in), static_cast<float*>(out), outer, len, inner, pro, s, ws, ws_bytes);
         case MYFA_F16:  return softmax_cols_any<_Float16, true>(static_cast<const _Float16*>(in), static_cast<_Float16*>(out), outer, len, inner, pro, s, ws, ws_bytes);

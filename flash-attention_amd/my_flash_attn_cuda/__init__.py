@@ -88,8 +88,23 @@ def my_softmax(inp, kernel_no=1):
     h, w = inp.shape
     out = torch.empty_like(inp)   # every element is written; no zero-fill pass
     with _on(inp):
-        _lib.check(_lib.lib.myfa_softmax_f32(inp.data_ptr(), out.data_ptr(), h, w, _stream()))
+        if not _rows_with_workspace(inp, out, h, w):
+            _lib.check(_lib.lib.myfa_softmax_f32(inp.data_ptr(), out.data_ptr(), h, w, _stream()))
     return out
+
+
+def _rows_with_workspace(inp, out, h, w):
+    """Few long rows (h far below the CU count, w beyond what a workgroup holds in registers): with a
+    workspace (torch's caching allocator, stream-ordered) the library splits each row over workgroups.
+    Returns False when the library would not split this shape."""
+    tag = _DTYPE_TAG[inp.dtype]
+    nbytes = _lib.lib.myfa_softmax_nd_ws_bytes(h, w, 1, tag)
+    if nbytes <= 0:
+        return False
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=inp.device)
+    _lib.check(_lib.lib.myfa_softmax_nd_ws(inp.data_ptr(), out.data_ptr(), h, w, 1, tag, 1.0, None, 1, 0,
+                                           ws.data_ptr(), nbytes, _stream()))
+    return True
 
 
 def softmax_rows(inp):
@@ -104,7 +119,8 @@ def softmax_rows(inp):
     h, w = inp.shape
     out = torch.empty_like(inp)
     with _on(inp):
-        _lib.check(_lib.lib.myfa_softmax(inp.data_ptr(), out.data_ptr(), h, w, _DTYPE_TAG[inp.dtype], _stream()))
+        if not _rows_with_workspace(inp, out, h, w):
+            _lib.check(_lib.lib.myfa_softmax(inp.data_ptr(), out.data_ptr(), h, w, _DTYPE_TAG[inp.dtype], _stream()))
     return out
 
 
@@ -153,8 +169,8 @@ def softmax(inp, dim=-1, scale=1.0, mask=None, causal=False):
     if causal and (dim != inp.dim() - 1 or inp.dim() < 2 or inp.shape[-1] != inp.shape[-2]):
         raise RuntimeError("causal=True needs dim to be the last dimension of (..., N, N) logits")
     with _on(inp):
-        # long columns: with a workspace (torch's caching allocator, stream-ordered) the library splits
-        # the rows of a column block over workgroups and reads the tensor once instead of twice
+        # long columns, or few long rows: with a workspace (torch's caching allocator, stream-ordered)
+        # the library splits them over workgroups
         nbytes = _lib.lib.myfa_softmax_nd_ws_bytes(outer, inp.shape[dim], inner, _DTYPE_TAG[inp.dtype])
         if nbytes > 0:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=inp.device)

@@ -113,19 +113,21 @@ int myfa_softmax_nd_ex(const void* in, void* out, int64_t outer, int64_t len, in
                        float scale, const float* add_mask, int64_t mask_outer, int flags, void* stream);
 
 /*
- * myfa_softmax_nd_ex with a caller workspace, for long columns (inner > 1 and more rows than one
- * workgroup's registers hold, e.g. [8192, 8192] or [16384, 16384] along dimension 0): without a
- * workspace such a column block is read twice (statistics, then values: 12 bytes per float32
- * element); with one its rows are split over workgroups that hold their slices in registers and
- * exchange (max, sum) pairs through the workspace: one read and one write (8 bytes per element).
- * myfa_softmax_nd_ws_bytes(outer, len, inner, dtype) is the size that lets the library do so (0: the
- * shape is not split -- rows, short columns, rows of fewer than eight 16-byte items, inner not a
- * multiple of the 16-byte item, more than 256 slices; a smaller workspace, NULL, or tensors that
- * are not 16-byte aligned fall back to what myfa_softmax_nd_ex does).  The library clears the part
- * of the workspace it needs cleared on `stream` itself; the contents before and after the call
- * mean nothing; it must stay untouched until the call's work on `stream` has finished, and two calls
+ * myfa_softmax_nd_ex with a caller workspace, for shapes that leave the chip empty when every slice
+ * along the softmax dimension is one workgroup's job:
+ *   long columns (inner > 1, more rows than one workgroup's registers hold) whose column blocks are
+ *   few, e.g. [100000, 512] along dimension 0: the rows of a column block are split over workgroups;
+ *   few long rows (inner == 1, outer < 256, len beyond 32768 float32 / 65536 16-bit elements), e.g.
+ *   [4, 4194304] or [16, 131072] logits: each row is split over workgroups.
+ * Two launches: the slices leave their (max, sum) pairs in the workspace and the workgroup that
+ * finishes a column block / row last merges them (nobody waits for anybody); the second launch
+ * re-reads and writes.  myfa_softmax_nd_ws_bytes(outer, len, inner, dtype) is the size that lets the
+ * library do so (0: the shape is not split; a smaller workspace, NULL, or tensors that are not
+ * 16-byte aligned fall back to what myfa_softmax_nd_ex does).  The library clears the part of the
+ * workspace it needs cleared on `stream` itself; the contents before and after the call mean
+ * nothing; it must stay untouched until the call's work on `stream` has finished, and two calls
  * that may overlap need a workspace each.  Same result as myfa_softmax_nd_ex up to float32 rounding
- * (exp(x - m_slice) * exp(m_slice - m) in place of exp(x - m)).  In-place is allowed.
+ * of the merge.  In-place is allowed.
  * No counterpart in the reference (its softmax is one workgroup per row, csrc/my_flash_attn/softmax.cu:459-487).
  */
 int64_t myfa_softmax_nd_ws_bytes(int64_t outer, int64_t len, int64_t inner, int dtype);

@@ -154,3 +154,53 @@ def test_workspace_argument_checks(mfa):
     assert _lib.lib.myfa_softmax_nd_ws_bytes(64, 31, 100, _lib.MYFA_F32) == 0
     assert _lib.lib.myfa_softmax_nd_ws_bytes(0, 5000, 64, _lib.MYFA_F32) == 0
     assert _lib.lib.myfa_softmax_nd_ws_bytes(1, 5000, 64, 77) == 0
+
+
+# few long rows (inner == 1): each row split over workgroups.  Aligned and off-grid widths, one row,
+# widths that leave a short last slice
+ROW_SHAPES = [(1, 1 << 20), (4, 300001), (16, 131072), (3, 40961), (100, 50257), (255, 33000)]
+
+
+@pytest.mark.parametrize("shape", ROW_SHAPES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_few_long_rows_split(mfa, shape, dtype):
+    torch.manual_seed(14)
+    h, w = shape
+    x = (torch.randn(h, w) * 3).to(dtype)
+    x[0, : w // 2] = float("-inf")                 # whole slices of -inf in the first row
+    xd = x.cuda()
+    nbytes = _ws_bytes(xd, 1)
+    # (16-bit rows up to 65536 wide fit a workgroup's registers and are not split)
+    assert (nbytes > 0) == (dtype == torch.float32 or w > 65536)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device="cuda")
+    rc, out = _call_ws(xd, 1, ws, nbytes)
+    assert rc == 0
+    rc, plain = _call_ws(xd, 1, None, 0)           # no workspace: one workgroup per row
+    assert rc == 0
+    assert float((out.float() - plain.float()).abs().max()) <= (1e-6 if dtype == torch.float32 else 1e-3)
+    ref = ref_cpu.softmax_dim(x.float().numpy(), 1)
+    tol = 0.0 if dtype == torch.float32 else LOWP_REL[dtype]
+    assert (np.abs(out.float().cpu().numpy() - ref) <= tol * ref + ATOL).all()
+    assert float(out[0, : w // 2].float().abs().max()) == 0.0
+    rc, again = _call_ws(xd, 1, ws, nbytes)        # the same workspace again, dirty
+    assert rc == 0 and torch.equal(again, out)
+    assert torch.equal(mfa.softmax(xd, dim=-1), out)
+    assert torch.equal(mfa.softmax_rows(xd), out)
+    if dtype == torch.float32:
+        assert torch.equal(mfa.my_softmax(xd, 5), out)
+
+
+def test_few_long_rows_fused_and_unsplit_shapes(mfa):
+    from my_flash_attn_cuda import _lib
+    torch.manual_seed(15)
+    h, w = 3, 70001
+    x, mask = torch.randn(h, w) * 2, torch.randn(w)
+    mask[:30000] = float("-inf")
+    out = mfa.softmax(x.cuda(), dim=-1, scale=0.7, mask=mask.cuda())
+    ref = torch.softmax(0.7 * x.double() + mask.double(), -1)
+    assert float((out.cpu() - ref.float()).abs().max()) <= ATOL
+    # rows enough for the chip, rows a workgroup holds in registers: not split
+    assert _lib.lib.myfa_softmax_nd_ws_bytes(256, 1 << 20, 1, _lib.MYFA_F32) == 0
+    assert _lib.lib.myfa_softmax_nd_ws_bytes(8, 32768, 1, _lib.MYFA_F32) == 0
+    assert _lib.lib.myfa_softmax_nd_ws_bytes(8, 65536, 1, _lib.MYFA_BF16) == 0
+    assert _lib.lib.myfa_softmax_nd_ws_bytes(8, 65544, 1, _lib.MYFA_BF16) > 0
