@@ -9,7 +9,7 @@
 //
 // Three kernels:
 //   softmax_rows_reg<TPR, V, VW>  row held in registers; TPR threads per row, V
-//                                 items of VW floats per thread (covers w <= 32768)
+//                                 items of VW floats per thread (covers w <= 65536)
 //   softmax_rows_stream<VW>       longer rows: online (max, sum) pass, then a
 //                                 second pass that re-reads and writes (12 B/elt)
 // An item is 16 bytes: VW = 4 floats, or 8 halves / bfloat16s (the element type E is a
@@ -20,6 +20,7 @@
 // first and the last item of a row are partial, and those are read and written element by element
 // (nothing outside the row is touched).  VW = 1 is left for tensors whose base is not 16-byte aligned.
 #include <algorithm>
+#include <type_traits>
 #include "softmax_common.h"
 #include "tuning.h"
 
@@ -29,26 +30,36 @@ namespace {
 
 // One item of a row under SHIFT: columns col0 .. col0 + VW - 1, of which those outside 0 .. w-1 do
 // not belong to the row (they read as -inf and are not written).
-template <typename E, int VW, bool NT, bool PRO>
-__device__ __forceinline__ void load_item(float (&x)[VW], const E* src, int64_t col0, int64_t row, int64_t w, const Prologue& pro) {
-    if (col0 >= 0 && col0 + VW <= w) {
+template <typename E, int VW, bool NT, bool PRO, typename I>
+__device__ __forceinline__ void load_item(float (&x)[VW], const E* src, I col0, int64_t row, I w, const Prologue& pro) {
+    if constexpr (!PRO) {
+        // The aligned 16 bytes are read whole even where they reach into the neighbouring row or, for
+        // the last item of the tensor, up to 12 bytes past its end: an aligned 16-byte group never
+        // crosses a page, so the read cannot fault; what is not the row's is replaced by -inf.
         vload<E, VW, NT>(x, src + col0);
-        if constexpr (PRO) prologue_row<VW>(x, pro, row, w, col0);
+        if (col0 < 0 || col0 + VW > w) {
+#pragma unroll
+            for (int c = 0; c < VW; ++c)
+                if (col0 + c < 0 || col0 + c >= w) x[c] = -INFINITY;
+        }
+    } else if (col0 >= 0 && col0 + VW <= w) {
+        vload<E, VW, NT>(x, src + col0);
+        prologue_row<VW>(x, pro, row, w, col0);
     } else {
 #pragma unroll
         for (int c = 0; c < VW; ++c) {
-            const int64_t col = col0 + c;
+            const I col = col0 + c;
             x[c] = -INFINITY;
             if (col >= 0 && col < w) {
                 float e[1] = {(float)src[col]};
-                if constexpr (PRO) prologue_row<1>(e, pro, row, w, col);
+                prologue_row<1>(e, pro, row, w, col);
                 x[c] = e[0];
             }
         }
     }
 }
-template <typename E, int VW, bool NT>
-__device__ __forceinline__ void store_item(E* dst, int64_t col0, int64_t w, const float (&x)[VW]) {
+template <typename E, int VW, bool NT, typename I>
+__device__ __forceinline__ void store_item(E* dst, I col0, I w, const float (&x)[VW]) {
     if (col0 >= 0 && col0 + VW <= w) {
         vstore<E, VW, NT>(dst + col0, x);
     } else {
@@ -97,20 +108,25 @@ softmax_rows_reg(const E* __restrict__ in, E* __restrict__ out, int64_t h, int64
 
     // item index of (v, thread): MAP 0 interleaves the threads of the row (item v*TPR + t);
     // MAP 1 gives each wave V consecutive 64-item pieces (a contiguous V KiB at VW = 4)
-    auto item = [&](int v) -> int64_t {
-        if constexpr (MAP == 0) return (int64_t)v * TPR + t;
-        else return ((int64_t)(t >> 6) * V + v) * 64 + (t & 63);
+    // (SHIFT: 32-bit columns -- a row held in registers is at most 65536 elements -- which saves the
+    // registers its per-item bounds need; the aligned builds keep the 64-bit arithmetic they were
+    // measured with: at 16384 x 16384 the 32-bit form of the same kernel is 5 % slower)
+    using I = std::conditional_t<SHIFT, int, int64_t>;
+    auto item = [&](int v) -> I {
+        if constexpr (MAP == 0) return (I)v * TPR + t;
+        else return ((I)(t >> 6) * V + v) * 64 + (t & 63);
     };
+    const I wi = (I)w;
     // SHIFT: the row starts `shift` elements past a 16-byte boundary; item i is columns i*VW - shift ..
     const int shift = SHIFT ? (int)((row * w) % VW) : 0;
     float x[V][VW];
     float mx = -INFINITY;
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-        const int64_t col = item(v) * VW - shift;
-        if (col < w) {
+        const I col = item(v) * VW - shift;
+        if (col < wi) {
             if constexpr (SHIFT) {
-                load_item<E, VW, (NTM & 1) != 0, PRO>(x[v], src, col, row, w, pro);
+                load_item<E, VW, (NTM & 1) != 0, PRO>(x[v], src, col, row, wi, pro);
             } else {
                 vload<E, VW, (NTM & 1) != 0>(x[v], src + col);
                 if constexpr (PRO) prologue_row<VW>(x[v], pro, row, w, col);
@@ -139,11 +155,11 @@ softmax_rows_reg(const E* __restrict__ in, E* __restrict__ out, int64_t h, int64
     const float inv = 1.0f / sum;
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-        const int64_t col = item(v) * VW - shift;
-        if (col < w) {
+        const I col = item(v) * VW - shift;
+        if (col < wi) {
 #pragma unroll
             for (int c = 0; c < VW; ++c) x[v][c] *= inv;
-            if constexpr (SHIFT) store_item<E, VW, (NTM & 2) != 0>(dst, col, w, x[v]);
+            if constexpr (SHIFT) store_item<E, VW, (NTM & 2) != 0>(dst, col, wi, x[v]);
             else vstore<E, VW, (NTM & 2) != 0>(dst + col, x[v]);
         }
     }
@@ -291,6 +307,7 @@ bool dispatch_reg(const E* in, E* out, int64_t h, int64_t w, hipStream_t s, cons
     MYFA_CASE(256, 1) MYFA_CASE(256, 2) MYFA_CASE(256, 4) MYFA_CASE(256, 8)
     MYFA_CASE(512, 2) MYFA_CASE(512, 4) MYFA_CASE(512, 8)
     MYFA_CASE(1024, 2) MYFA_CASE(1024, 4) MYFA_CASE(1024, 8)
+    if constexpr (VW == 4) { MYFA_CASE(1024, 16) }
 #undef MYFA_CASE
     return false;
 }
@@ -318,6 +335,7 @@ Shape choose_shape(int64_t items, int64_t tensor_bytes, int vw, bool shifted = f
         else if (items <= 2048) { sh.tpr = 1024; sh.v = 2; }
         else if (items <= 4096) { sh.tpr = 1024; sh.v = 4; }
         else if (items <= 8192) { sh.tpr = 1024; sh.v = 8; }
+        else if (items <= 16384 && vw == 4) { sh.tpr = 1024; sh.v = 16; }
         return sh;
     }
     if (vw == 8) {
@@ -339,6 +357,7 @@ Shape choose_shape(int64_t items, int64_t tensor_bytes, int vw, bool shifted = f
     else if (items <= 2048) { sh.tpr = 1024; sh.v = 2; sh.map = 1; }
     else if (items <= 4096) { sh.tpr = 1024; sh.v = 8; sh.map = 1; }
     else if (items <= 8192) { sh.tpr = 1024; sh.v = 8; sh.pad = 27000; }
+    else if (items <= 16384) { sh.tpr = 1024; sh.v = 16; }
     return sh;
 }
 
