@@ -368,9 +368,9 @@ struct RowSplit {
     size_t count_bytes = 0, bytes = 0;     // workspace: u32 count[h] (zero at launch), padded; float fin[h][2], part[h][nsplit][2]
 };
 // items: 16-byte items per row (covering groups for rows off the 16-byte grid)
-RowSplit rows_split_plan(int64_t h, int64_t items) {
+RowSplit rows_split_plan(int64_t h, int64_t items, int vw) {
     RowSplit p;
-    if (items <= 8192 || h >= 256) return p;          // the register-resident kernel, or rows enough for the chip
+    if (items <= (vw == 4 ? 16384 : 8192) || h >= 256) return p;   // the register-resident kernel, or rows enough for the chip
     const int64_t nsplit = std::min<int64_t>({1024, cdiv((int64_t)1024, h), items / 2048});
     if (nsplit < 2) return p;
     p.ips = cdiv(cdiv(items, nsplit), (int64_t)1024) * 1024;
@@ -402,7 +402,7 @@ int softmax_any(const E* in, E* out, int64_t h, int64_t w, const Prologue& pro, 
                    : shifted ? dispatch_reg<E, VWV, PRO, true>(in, out, h, w, s, sh, pro)
                              : dispatch_reg<E, 1, PRO>(in, out, h, w, s, sh, pro);
     if (!done) {
-        const RowSplit p = (vec || shifted) ? rows_split_plan(h, shifted ? cdiv(w + VWV - 1, (int64_t)VWV) : w / VWV) : RowSplit{};
+        const RowSplit p = (vec || shifted) ? rows_split_plan(h, shifted ? cdiv(w + VWV - 1, (int64_t)VWV) : w / VWV, VWV) : RowSplit{};
         if (ws != nullptr && p.nsplit > 1 && ws_bytes >= p.bytes) {
             if (const hipError_t e = hipMemsetAsync(ws, 0, p.count_bytes, s); e != hipSuccess)
                 return fail(MYFA_E_LAUNCH, "softmax: clearing the workspace: %s", hipGetErrorString(e));
@@ -458,7 +458,7 @@ size_t softmax_rows_ws_bytes(int64_t h, int64_t w, int dtype) {
     if (h <= 0 || w <= 0) return 0;
     const int64_t vw = dtype == MYFA_F32 ? 4 : (dtype == MYFA_F16 || dtype == MYFA_BF16) ? 8 : 0;
     if (vw == 0) return 0;
-    return rows_split_plan(h, w % vw == 0 ? w / vw : cdiv(w + vw - 1, vw)).bytes;
+    return rows_split_plan(h, w % vw == 0 ? w / vw : cdiv(w + vw - 1, vw), (int)vw).bytes;
 }
 
 }  // namespace myfa

@@ -117,7 +117,7 @@ int myfa_softmax_nd_ex(const void* in, void* out, int64_t outer, int64_t len, in
  * along the softmax dimension is one workgroup's job:
  *   long columns (inner > 1, more rows than one workgroup's registers hold) whose column blocks are
  *   few, e.g. [100000, 512] along dimension 0: the rows of a column block are split over workgroups;
- *   few long rows (inner == 1, outer < 256, len beyond 32768 float32 / 65536 16-bit elements), e.g.
+ *   few long rows (inner == 1, outer < 256, len beyond 65536 elements), e.g.
  *   [4, 4194304] or [16, 131072] logits: each row is split over workgroups.
  * Two launches: the slices leave their (max, sum) pairs in the workspace and the workgroup that
  * finishes a column block / row last merges them (nobody waits for anybody); the second launch
