@@ -10,8 +10,8 @@ collective on the timed path.  Rank 0 prints ONE JSON line:
   metric / value   whole-job attention-forward TFLOP/s (4*B*H*N^2*d flops per pass per GPU),
                    inputs resident in HBM, max-over-ranks wall time between barriers
   roofline         the attention kernel against the dense bf16 MFMA peak (2.5 PFLOP/s):
-                   algorithmic flops per launch / mean launch duration from HIP events
-                   recorded around every timed launch on the launch stream
+                   algorithmic flops per launch / mean launch duration = one HIP event pair
+                   around the K timed launches, on the launch stream, / K
   cpu_baseline     the C oracle (float32 arithmetic, OpenMP) timed on this host's cores on
                    a bounded sample of the same workload (rank 0, N=1 only)
   softmax_sweep    row-softmax GB/s (algorithmic 8 B/element) at n x n, n = 4096..32768,
@@ -88,17 +88,20 @@ def bench_attention(mfa, B, H, N, d, dtype, steps, warmup, world, scale, causal=
         out = mfa.flash_attn_fwd(q, k, v, scale=scale, causal=causal)
     for _ in range(warmup):
         out = mfa.flash_attn_fwd(q, k, v, scale=scale, causal=causal)
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
-    stops = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+    # One pair of HIP events around the timed region, on the stream the launches go to: an event
+    # between two launches is a barrier packet that drains the GPU before the next kernel starts, so
+    # a pair per launch would put a bubble into every step.  Mean launch duration = region / K (it
+    # includes the gaps between back-to-back launches, so it bounds the kernel's time from above).
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    start.record()
     for i in range(steps):
-        starts[i].record()
         out = mfa.flash_attn_fwd(q, k, v, scale=scale, causal=causal)
-        stops[i].record()
+    stop.record()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -108,10 +111,9 @@ def bench_attention(mfa, B, H, N, d, dtype, steps, warmup, world, scale, causal=
         t = torch.tensor([wall], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
-    kern_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, stops))
-    mean_ms = sum(kern_ms) / len(kern_ms)
+    mean_ms = start.elapsed_time(stop) / steps
     assert bool(torch.isfinite(out.float()).all())
-    return wall, mean_ms, kern_ms[len(kern_ms) // 2], (q, k, v, out)
+    return wall, mean_ms, (q, k, v, out)
 
 
 def bench_config5_strong(mfa, rank, world, use_dist, steps=4, warm=2):
@@ -441,7 +443,7 @@ def main():
 
     B, H, N, d, dtype = WORKLOADS[args.workload]
     scale = d ** -0.5 if args.scale == "rsqrt_d" else 1.0
-    wall, mean_ms, med_ms, (_, _, _, out) = bench_attention(mfa, B, H, N, d, dtype, args.steps, args.warmup, world, scale, args.causal, use_dist)
+    wall, mean_ms, (_, _, _, out) = bench_attention(mfa, B, H, N, d, dtype, args.steps, args.warmup, world, scale, args.causal, use_dist)
     # Verification only, outside the timed region: every rank's per-head output checksums are
     # gathered over RCCL (xGMI); all ranks must end up with the same, finite table.
     from my_flash_attn_cuda import sharding
@@ -486,7 +488,7 @@ def main():
                      "traffic_detail": traffic, "algorithmic_bytes": 4.0 * B * H * N * d * 2,
                      "kernel": "attn_fwd_mfma16_kernel" if not args.causal else "attn_fwd_mfma_pp_kernel",
                      "launch_ms_mean": round(mean_ms, 4),
-                     "launch_ms_median": round(med_ms, 4), "flops_per_launch": flops},
+                     "launch_timing": "one HIP event pair around the K timed launches / K", "flops_per_launch": flops},
         "config5_strong_scaling": config5,
     }
     result["verify"] = {"gathered_head_checksums": int(table.shape[0]), "gather_ms_untimed_path": round(gather_ms, 3)}
