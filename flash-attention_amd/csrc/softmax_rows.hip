@@ -236,7 +236,10 @@ softmax_rows_stream(const E* __restrict__ in, E* __restrict__ out, int64_t h, in
                 put(parts + 2 * split, row_mx);
                 put(parts + 2 * split + 1, row_sum);
             }
-            __syncthreads();       // (waits for the stores above to have completed)
+            // the pair must have arrived (device-scope stores are acknowledged at the coherence point)
+            // before this workgroup counts itself in: a workgroup-scope barrier alone does not wait for it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
             if (t == 0)
                 s_last = __hip_atomic_fetch_add(count + row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nsplit - 1);
             __syncthreads();

@@ -208,7 +208,10 @@ softmax_cols_stream(const E* __restrict__ in, E* __restrict__ out, int64_t len, 
             }
         }
         __shared__ unsigned s_last;
-        __syncthreads();       // (waits for the stores above to have completed)
+        // the pairs must have arrived (device-scope stores are acknowledged at the coherence point)
+        // before this workgroup counts itself in: a workgroup-scope barrier alone does not wait for them
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         if (threadIdx.x == 0)
             s_last = __hip_atomic_fetch_add(count + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nsplit - 1);
         __syncthreads();
