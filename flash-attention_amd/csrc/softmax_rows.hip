@@ -165,6 +165,9 @@ softmax_rows_reg(const E* __restrict__ in, E* __restrict__ out, int64_t h, int64
     }
 }
 
+// Counters of different rows sit 256 bytes apart: atomics on one cache line are served one after the other.
+constexpr int kCountStride = 64;
+
 __device__ __forceinline__ void put(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float get(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -241,7 +244,7 @@ softmax_rows_stream(const E* __restrict__ in, E* __restrict__ out, int64_t h, in
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (t == 0)
-                s_last = __hip_atomic_fetch_add(count + row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nsplit - 1);
+                s_last = __hip_atomic_fetch_add(count + row * kCountStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nsplit - 1);
             __syncthreads();
             if (!s_last) return;   // uniform over the workgroup
             // at most 1024 slices: one pair per thread
@@ -368,7 +371,7 @@ Shape choose_shape(int64_t items, int64_t tensor_bytes, int vw, bool shifted = f
 struct RowSplit {
     int nsplit = 0;
     int64_t ips = 0;                       // items per slice, a multiple of the 1024 threads
-    size_t count_bytes = 0, bytes = 0;     // workspace: u32 count[h] (zero at launch), padded; float fin[h][2], part[h][nsplit][2]
+    size_t count_bytes = 0, bytes = 0;     // workspace: u32 count[h], 256 bytes apart (zero at launch); float fin[h][2], part[h][nsplit][2]
 };
 // items: 16-byte items per row (covering groups for rows off the 16-byte grid)
 RowSplit rows_split_plan(int64_t h, int64_t items, int vw) {
@@ -378,7 +381,7 @@ RowSplit rows_split_plan(int64_t h, int64_t items, int vw) {
     if (nsplit < 2) return p;
     p.ips = cdiv(cdiv(items, nsplit), (int64_t)1024) * 1024;
     p.nsplit = (int)cdiv(items, p.ips);
-    p.count_bytes = ((size_t)h * 4 + 255) / 256 * 256;
+    p.count_bytes = (size_t)h * kCountStride * 4;
     p.bytes = p.count_bytes + (size_t)h * (size_t)(1 + p.nsplit) * 2 * sizeof(float);
     return p;
 }

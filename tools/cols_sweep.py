@@ -33,7 +33,7 @@ def run(t, length, w, dtype, arms, iters=20):
 
 if __name__ == "__main__":
     t = Tuned()
-    arms = (-1, 512, 1024, 2048, 4096)
-    for length, w in ((8192, 256), (8192, 1024), (8192, 4096), (8192, 8192), (16384, 16384), (16384, 4096), (2000, 8192), (100000, 512), (1000001, 24)):
+    arms = (-1, 64, 128, 256, 512, 1024)
+    for length, w in ((8192, 256), (8192, 1024), (8192, 4096), (16384, 4096), (2000, 8192), (100000, 512), (1000001, 24)):
         run(t, length, w, torch.float32, arms)
-    run(t, 8192, 8192, torch.bfloat16, arms)
+    run(t, 8192, 1024, torch.bfloat16, arms)
