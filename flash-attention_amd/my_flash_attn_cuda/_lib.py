@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MYFA_LIBRARY") or os.path.join(_HERE, "libmyfa_gfx950.so")
 TUNING_LIB_PATH = os.path.join(_HERE, "libmyfa_gfx950_tuning.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MYFA_F32, MYFA_F16, MYFA_BF16 = 0, 1, 2
 
 # every symbol include/myfa.h declares

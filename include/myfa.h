@@ -32,7 +32,9 @@
 extern "C" {
 #endif
 
-#define MYFA_ABI_VERSION 1
+/* 2: the entry points with a caller workspace or the library's own (…_ws, …_static_ws), the fused
+ * softmax prologue (…_nd_ex) and 16-bit head dims up to 256 were added; nothing of version 1 changed. */
+#define MYFA_ABI_VERSION 2
 
 enum {
     MYFA_OK = 0,
