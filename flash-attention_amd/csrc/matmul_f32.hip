@@ -266,9 +266,13 @@ int matmul_f32(const float* a, const float* b, float* c, int64_t m, int64_t k, i
     // (the vector path's 32-bit buffer offsets cover 128 rows of A and 16 rows of B)
     const bool vec = k % 4 == 0 && n % 4 == 0 && k <= (1 << 21) && n <= (1 << 24) &&
                      ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) % 16 == 0);
-    // 128 x 128 blocks once they fill the chip twice over (the tuning flavour of the library can force either kernel)
+    // 128 x 128 blocks (142 TFLOP/s at best against the 64 x 64 kernel's 137) once they fill the chip
+    // twice over -- 512 of them run at a time -- and only while their rounds of 512 are at least 90 %
+    // full: 3072^3 is 576 blocks, 104 TFLOP/s against 131 with the smaller blocks; 4608^3 118 against
+    // 131.  The tuning flavour of the library can force either kernel
     const int force = tuning().matmul_block;
-    const bool large = force ? force == 128 : cdiv(n, kLN) * cdiv(m, kLM) >= 512;
+    const int64_t w128 = cdiv(n, kLN) * cdiv(m, kLM);
+    const bool large = force ? force == 128 : (w128 >= 512 && w128 * 10 >= cdiv(w128, (int64_t)512) * 512 * 9);
     if (large) {
         const dim3 g128((unsigned)cdiv(n, kLN), (unsigned)cdiv(m, kLM));
         if (vec) launch_kernel(sgemm_mfma_128_kernel<true>, g128, dim3(256), 0, s, a, b, c, (int)m, (int)k, (int)n);
