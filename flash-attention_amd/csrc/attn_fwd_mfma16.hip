@@ -132,7 +132,7 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
     // chunk: lane L of piece pc owns 16-byte unit u = 64 pc + L, which by the image formula is
     // (row, chunk) below.  Rows past N read as zero (buffer bounds check).
     const unsigned head_bytes = (unsigned)N * gd * 2;
-    const int tile_gb = kBKV16 * gd * 2;          // bytes of one 64-row tile in memory
+    [[maybe_unused]] const int tile_gb = kBKV16 * gd * 2;          // bytes of one 64-row tile in memory
     const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)(Kg + hoff), 0, head_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(Vg + hoff), 0, head_bytes, 0x00020000);
     [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);

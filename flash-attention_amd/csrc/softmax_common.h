@@ -52,6 +52,15 @@ __device__ __forceinline__ void vstore(E* p, const float (&src)[VW]) {
     }
 }
 
+// Values that cross workgroups inside one launch (the (max, sum) pairs of the split kernels) are
+// written and read with device-scope accesses: coherent across the per-XCD L2s without any
+// workgroup writing back or invalidating a whole cache.
+__device__ __forceinline__ void put(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float get(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Arrival counters of different rows / column blocks sit 256 bytes apart: atomics on one cache line
+// are served one after the other (1024 arrivals on 8 adjacent counters took 34 us).
+constexpr int kCountStride = 64;
+
 // x[0..VW) = elements j .. j+VW-1 along the softmax dimension of outer index o (inner == 1)
 template <int VW>
 __device__ __forceinline__ void prologue_row(float (&x)[VW], const Prologue& p, int64_t o, int64_t len, int64_t j) {

@@ -165,12 +165,6 @@ softmax_rows_reg(const E* __restrict__ in, E* __restrict__ out, int64_t h, int64
     }
 }
 
-// Counters of different rows sit 256 bytes apart: atomics on one cache line are served one after the other.
-constexpr int kCountStride = 64;
-
-__device__ __forceinline__ void put(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float get(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 // Rows too long to hold in registers: 1024-thread workgroups.
 //   PHASE 0: one workgroup per row does both passes (grid = h).
 // With a workspace, few long rows (h far below the CU count) are also split into `nsplit` slices

@@ -109,13 +109,6 @@ softmax_cols_reg(const E* __restrict__ in, E* __restrict__ out, int64_t len, int
     }
 }
 
-// Counters of different column blocks sit 256 bytes apart: atomics on one cache line are served one
-// after the other (~33 ns each, measured: 1024 arrivals on 8 adjacent counters took 34 us).
-constexpr int kCountStride = 64;
-
-__device__ __forceinline__ void put(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float get(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 // Any len: BLOCK = 256, 512 or 1024 threads, rows taken U at a time per thread so that U loads are in
 // flight and the running max is refreshed once per U rows.
 //   PHASE 0: one workgroup per column block does both passes (grid = column blocks).
