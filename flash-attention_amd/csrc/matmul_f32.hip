@@ -29,7 +29,7 @@ constexpr int kBS = kBN + 4;     // B block row stride in LDS (floats)
 template <bool VEC>
 __global__ void __launch_bounds__(256)
 sgemm_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
-                  int m, int k, int n) {
+                  int m, int k, int n, int kslice) {
     // two copies of each block: chunk i + 1 is published while chunk i is multiplied, one barrier per chunk
     __shared__ float As[2][kBM * kAS];
     __shared__ __attribute__((aligned(16))) float Bs[2][kBK * kBS];
@@ -38,6 +38,11 @@ sgemm_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, floa
     const int j = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;       // the wave's 32 x 32 corner in the block
+    // k split over gridDim.z workgroups (small problems: one 4-wave workgroup per CU cannot hide its
+    // own load latency): this one sums k in [kbeg, kend) and adds its block to C, which the launcher
+    // has zeroed, with float atomics.  Two addends per element, so the result does not depend on
+    // which arrives first.  kslice is a multiple of kBK; rows of A stay k apart.
+    const int kbeg = blockIdx.z * kslice, kend = min(k, kbeg + kslice);
 
     // staging: thread t moves A[m0 + t/4][k0 + 4(t%4) ..+3] and B[k0 + t/16][n0 + 4(t%16) ..+3]
     const int ar = tid >> 2, ac = (tid & 3) * 4;
@@ -51,13 +56,13 @@ sgemm_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, floa
     auto fetch = [&](int k0, int slot) __attribute__((always_inline)) {
         if constexpr (VEC) {
 #if defined(__HIP_DEVICE_COMPILE__)
-            const int arows = min(kBM, m - m0), brows = min(kBK, k - k0);
-            const bool any = k0 < k;
-            const unsigned abytes = any ? (unsigned)(((size_t)(arows - 1) * k + (k - k0)) * 4) : 0u;
+            const int arows = min(kBM, m - m0), brows = min(kBK, kend - k0);
+            const bool any = k0 < kend;
+            const unsigned abytes = any ? (unsigned)(((size_t)(arows - 1) * k + (kend - k0)) * 4) : 0u;
             const unsigned bbytes = any ? (unsigned)(((size_t)(brows - 1) * n + (n - n0)) * 4) : 0u;
             const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * k + (any ? k0 : 0)), 0, abytes, 0x00020000);
             const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)(B + (size_t)(any ? k0 : 0) * n + n0), 0, bbytes, 0x00020000);
-            const int aoff = k0 + ac < k ? ac * 4 : (int)0x80000000;
+            const int aoff = k0 + ac < kend ? ac * 4 : (int)0x80000000;
             const int boff = n0 + bc < n ? bc * 4 : (int)0x80000000;
             ra[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, aoff + ar * k * 4, 0, 0));
             rb[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, boff + br * n * 4, 0, 0));
@@ -70,10 +75,10 @@ sgemm_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, floa
                 const float* p = A + (size_t)am * k + ak;
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    if (ak + t < k) ra[slot][t] = p[t];
+                    if (ak + t < kend) ra[slot][t] = p[t];
             }
             const int bk = k0 + br, bn = n0 + bc;
-            if (bk < k) {
+            if (bk < kend) {
                 const float* p = B + (size_t)bk * n + bn;
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
@@ -95,15 +100,15 @@ sgemm_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, floa
 
     static_assert(kPF % 2 == 0, "the LDS copy of a chunk is chosen by the parity of its slot");
 #pragma unroll
-    for (int p = 0; p < kPF; ++p) fetch(p * kBK, p);      // (past the end: zero-filled, published, never read)
+    for (int p = 0; p < kPF; ++p) fetch(kbeg + p * kBK, p);      // (past the end: zero-filled, published, never read)
     publish(0, 0);
-    fetch(kPF * kBK, 0);
+    fetch(kbeg + kPF * kBK, 0);
     __syncthreads();
-    for (int kb = 0; kb < k; kb += kPF * kBK) {
+    for (int kb = kbeg; kb < kend; kb += kPF * kBK) {
 #pragma unroll
         for (int p = 0; p < kPF; ++p) {
             const int k0 = kb + p * kBK;
-            if (k0 < k) {                                  // uniform over the workgroup
+            if (k0 < kend) {                               // uniform over the workgroup
                 // chunk k0 is in copy p & 1; the next chunk goes into the other copy (last read one
                 // barrier ago) and its registers are refilled with the chunk kPF further on
                 publish((p + 1) % kPF, (p + 1) & 1);
@@ -134,7 +139,10 @@ sgemm_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B, floa
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm + 16 * a + 4 * g + r, col = n0 + wn + 16 * b + j;
-                if (row < m && col < n) C[(size_t)row * n + col] = acc[a][b][r];
+                if (row < m && col < n) {
+                    if (gridDim.z > 1) __hip_atomic_fetch_add(&C[(size_t)row * n + col], acc[a][b][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else C[(size_t)row * n + col] = acc[a][b][r];
+                }
             }
 }
 
@@ -279,9 +287,24 @@ int matmul_f32(const float* a, const float* b, float* c, int64_t m, int64_t k, i
         else     launch_kernel(sgemm_mfma_128_kernel<false>, g128, dim3(256), 0, s, a, b, c, (int)m, (int)k, (int)n);
         return check_launch("matmul_f32");
     }
-    const dim3 grid((unsigned)cdiv(n, kBN), (unsigned)cdiv(m, kBM));
-    if (vec) launch_kernel(sgemm_mfma_kernel<true>, grid, dim3(256), 0, s, a, b, c, (int)m, (int)k, (int)n);
-    else     launch_kernel(sgemm_mfma_kernel<false>, grid, dim3(256), 0, s, a, b, c, (int)m, (int)k, (int)n);
+    // Up to three workgroups per CU and a long k: two workgroups share each block's k range (C zeroed
+    // first, two atomic adds per element -- the same value whichever comes first).  Measured:
+    // 1024 x 4096 x 1024 115 -> 91 us, 128 x 8192 x 128 201 -> 106 us, 1536^3 85 -> 74 us; 1024^3 unchanged.
+    const int64_t w64 = cdiv(n, (int64_t)kBN) * cdiv(m, (int64_t)kBM);
+    const int split_knob = tuning().matmul_ksplit;
+    const bool split = split_knob ? split_knob > 1 : (w64 <= 768 && k >= 512);
+    int kslice = (int)k, zs = 1;
+    if (split) {
+        kslice = (int)(cdiv(cdiv(k, (int64_t)2), (int64_t)kBK) * kBK);
+        zs = (int)cdiv(k, (int64_t)kslice);
+        if (zs > 1) {
+            if (const hipError_t e = hipMemsetAsync(c, 0, (size_t)m * (size_t)n * sizeof(float), s); e != hipSuccess)
+                return fail(MYFA_E_LAUNCH, "matmul: clearing the output: %s", hipGetErrorString(e));
+        }
+    }
+    const dim3 grid((unsigned)cdiv(n, kBN), (unsigned)cdiv(m, kBM), (unsigned)zs);
+    if (vec) launch_kernel(sgemm_mfma_kernel<true>, grid, dim3(256), 0, s, a, b, c, (int)m, (int)k, (int)n, kslice);
+    else     launch_kernel(sgemm_mfma_kernel<false>, grid, dim3(256), 0, s, a, b, c, (int)m, (int)k, (int)n, kslice);
     return check_launch("matmul_f32");
 }
 

@@ -33,6 +33,8 @@ struct Tuning {
     int softmax_split_wgs = 0;
     // float32 matmul block edge: 0 = library's choice, 64 or 128
     int matmul_block = 0;
+    // float32 matmul, 64 x 64 kernel: 0 = library's choice, 1 = k never split, 2 = k split over two workgroups
+    int matmul_ksplit = 0;
 };
 
 #ifdef MYFA_TUNING
