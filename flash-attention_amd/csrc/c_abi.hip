@@ -241,6 +241,7 @@ int myfa_tuning_set(const char* key, double value) {
     else if (k == "softmax_nt") t.softmax_shape[3] = (int)value;
     else if (k == "softmax_pad") t.softmax_shape[4] = (int)value;
     else if (k == "softmax_split_wgs") t.softmax_split_wgs = (int)value;
+    else if (k == "softmax_cols_big") t.softmax_cols_big = (int)value;
     else return fail(MYFA_E_INVALID, "tuning: unknown key '%s'", k.c_str());
     return MYFA_OK;
 }

@@ -31,6 +31,8 @@ struct Tuning {
     // column softmax with the rows of a column block split over workgroups: workgroup count the split
     // aims at (0 = the default, 1024; -1 = never split, as without a workspace)
     int softmax_split_wgs = 0;
+    // column softmax, 1024-thread register-resident kernel: 0 = library's choice, -1 = never
+    int softmax_cols_big = 0;
     // float32 matmul block edge: 0 = library's choice, 64 or 128
     int matmul_block = 0;
     // float32 matmul, 64 x 64 kernel: 0 = library's choice, 1 = k never split, 2 = k split over two workgroups

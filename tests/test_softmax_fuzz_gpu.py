@@ -107,3 +107,18 @@ def test_fuzz_columns(mfa, case):
         out = mfa.softmax(x, dim=1, scale=1.3, mask=mask)
         ref = torch.softmax(1.3 * x.double() + mask.double(), 1)
     _check(out, ref, dtype)
+
+
+# the 1024-thread register-resident column kernel: 256-byte row segments up to 1024 rows, 128-byte
+# ones up to 2048, ragged last column block, with and without the prologue
+@pytest.mark.parametrize("shape,dim", [((16, 1000, 1100), 1), ((8, 1500, 2048), 1), ((2048, 8192), 0), ((300, 1024, 64), 1),
+                                       ((2, 4, 1025, 1024), 2)])
+def test_long_register_columns(mfa, shape, dim):
+    torch.manual_seed(33)
+    x = torch.randn(*shape, device="cuda") * 3
+    idx = [0] * len(shape)
+    idx[dim] = slice(0, shape[dim] // 2)
+    x[tuple(idx)] = float("-inf")                        # leading -inf along the reduced dimension of one slice
+    _check(mfa.softmax(x, dim=dim), torch.softmax(x.double(), dim), torch.float32)
+    mask = torch.randn(*shape[dim:], device="cuda")
+    _check(mfa.softmax(x, dim=dim, scale=0.5, mask=mask), torch.softmax(0.5 * x.double() + mask.double(), dim), torch.float32)
