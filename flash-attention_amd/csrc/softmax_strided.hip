@@ -10,7 +10,7 @@
 // threads share the rows of the column block (row ty, ty + TY, ...).  Per column the TY partial
 // (max, sum) pairs meet in LDS.
 //   softmax_cols_reg<R>   len <= R * TY: the column block is held in registers, 1 read + 1 write
-//                         (256 threads; 1024 threads for float32 columns of up to 2048 rows)
+//                         (256 threads; 1024 threads for columns of up to 2048 float32 / 1024 16-bit rows)
 //   softmax_cols_stream   any len: online (max, sum) pass, then a pass that re-reads and writes
 //                         (256 threads, or 512 / 1024 for long columns)
 // VW = 4 floats or 8 halves needs inner % VW == 0 and 16-byte aligned bases; otherwise VW = 1.
@@ -304,16 +304,16 @@ int reg_tx(int64_t outer, int64_t len, int64_t inner, size_t esize) {
     return 0;
 }
 
-// TX of the 1024-thread register-resident kernel (16-byte items of four floats), 0 when it does
-// not apply: the 256-thread one does, the column block does not fit 16 rows per thread, or there
-// are too few column blocks for the chip.
-inline int reg_tx_big(int64_t outer, int64_t len, int64_t inner) {
-    if (reg_tx<4>(outer, len, inner, 4) != 0) return 0;
-    const int64_t items = cdiv(inner, (int64_t)4);
-    const int knob = tuning().softmax_cols_big;
-    if (knob < 0) return 0;
+// TX of the 1024-thread register-resident kernel (16-byte items), 0 when it does not apply: the
+// 256-thread one does, the column block does not fit 64 floats per thread, or there are too few
+// column blocks for the chip.
+template <int VW>
+int reg_tx_big(int64_t outer, int64_t len, int64_t inner, size_t esize) {
+    if (VW == 1 || reg_tx<VW>(outer, len, inner, esize) != 0) return 0;
+    const int64_t items = cdiv(inner, (int64_t)VW);
+    if (tuning().softmax_cols_big < 0) return 0;
     for (const int tx : {16, 8}) {      // (64-byte segments lose to the two-pass form: 2.7 against 3.5-3.8 TB/s at 4096 rows)
-        if (items > tx / 2 && cdiv(len, (int64_t)(1024 / tx)) <= 16 && outer * cdiv(items, (int64_t)tx) >= 256) return tx;
+        if (items > tx / 2 && cdiv(len, (int64_t)(1024 / tx)) <= 64 / VW && outer * cdiv(items, (int64_t)tx) >= 256) return tx;
     }
     return 0;
 }
@@ -331,7 +331,7 @@ template <int VW>
 SplitPlan split_plan(int64_t outer, int64_t len, int64_t inner, size_t esize) {
     SplitPlan p;
     if (reg_tx<VW>(outer, len, inner, esize) != 0) return p;
-    if (VW == 4 && reg_tx_big(outer, len, inner) != 0) return p;
+    if (reg_tx_big<VW>(outer, len, inner, esize) != 0) return p;
     const int64_t items = cdiv(inner, (int64_t)VW);
     int tx = 4;
     for (const int t : {16, 8}) if (items > t / 2) { tx = t; break; }
@@ -368,11 +368,10 @@ int launch_cols(const E* in, E* out, int64_t outer, int64_t len, int64_t inner, 
     }
     MYFA_REG(64) MYFA_REG(16) MYFA_REG(8) MYFA_REG(4)
 #undef MYFA_REG
-    // The same with 1024 threads, for columns four times as long (float32 items only: eight-element
-    // items would need 128 registers of column data): 256-byte row segments up to 1024 rows, 128-byte
-    // ones up to 2048.
-    if constexpr (VW == 4) {
-        if (const int btx = reg_tx_big(outer, len, inner); btx != 0) {
+    // The same with 1024 threads, for columns four times as long: 256-byte row segments up to
+    // 16 * 64 rows of float32 (8 * 64 of 16-bit elements), 128-byte ones up to twice that.
+    if constexpr (VW > 1) {
+        if (const int btx = reg_tx_big<VW>(outer, len, inner, sizeof(E)); btx != 0) {
             const int64_t nchunk = cdiv(items, (int64_t)btx);
             const dim3 g((unsigned)blocks(btx)), b(1024);
             if (btx == 16) launch_kernel((softmax_cols_reg<E, 16, VW, RMAX, PRO, 1024>), g, b, 0, s, in, out, len, inner, nchunk, pro);

@@ -122,3 +122,6 @@ def test_long_register_columns(mfa, shape, dim):
     _check(mfa.softmax(x, dim=dim), torch.softmax(x.double(), dim), torch.float32)
     mask = torch.randn(*shape[dim:], device="cuda")
     _check(mfa.softmax(x, dim=dim, scale=0.5, mask=mask), torch.softmax(0.5 * x.double() + mask.double(), dim), torch.float32)
+    if shape[dim] <= 1024:                               # 16-bit elements: half the rows
+        xh = x.to(torch.bfloat16)
+        _check(mfa.softmax(xh, dim=dim), torch.softmax(xh.double(), dim), torch.bfloat16)
