@@ -214,10 +214,11 @@ def bench_softmax_sweep(mfa, iters=20):
 
 
 def bench_softmax_dim(mfa):
-    """softmax along a non-last dimension: register-resident column blocks, streamed columns, and tall
-    narrow tensors (rows of a column block split over workgroups)."""
+    """softmax along a non-last dimension: register-resident column blocks (256 threads; 1024 for the
+    2048-row columns), streamed columns, and tall narrow tensors (rows of a column block split over
+    workgroups)."""
     res = []
-    for shape, dim in (((256, 64, 64, 64), 1), ((64, 128, 16384), 1), ((8192, 8192), 0), ((16384, 4096), 0), ((100000, 512), 0)):
+    for shape, dim in (((256, 64, 64, 64), 1), ((64, 128, 16384), 1), ((4, 8, 2048, 2048), 2), ((8192, 8192), 0), ((16384, 4096), 0), ((100000, 512), 0)):
         xs = [torch.randn(*shape, dtype=torch.float32, device="cuda") for _ in range(3)]
         i = [0]
 
@@ -249,8 +250,19 @@ def bench_matmul_f32(mfa):
     return res
 
 
-def _median_ms(fn, iters=15, warm=3):
+def _median_ms(fn, iters=15, warm=3, settle_s=0.06):
+    """Median HIP-event time of fn().  After the `warm` calls the GPU is kept busy with fn for
+    another settle_s seconds (at most 200 calls) before anything is timed: coming from a different
+    kind of load (or from idle) the clocks take ~50 ms to settle, and a 4096^3 SGEMM timed over its
+    first 13 launches reads 125 TFLOP/s where every later launch runs at 141."""
     for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn()
+    torch.cuda.synchronize()
+    one = max(time.perf_counter() - t0, 1e-6)
+    for _ in range(min(200, int(settle_s / one))):
         fn()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     torch.cuda.synchronize()
