@@ -3,9 +3,12 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|config3|config5]
 
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL); every rank runs
-the same per-GPU workload on its own (batch x head) shard -- weak scaling, no
-collective on the timed path.  Rank 0 prints ONE JSON line:
+N > 1 runs one rank per GPU under torch.distributed.run (RCCL).  Started plainly
+(`python bench.py --gpus N`, no WORLD_SIZE in the environment) the script starts that launcher
+itself as a child process -- before anything touches the GPU -- relays rank 0's JSON line and
+exits with the child's status; started by a launcher it is a rank and checks that the world it
+finds is the --gpus it was asked for.  Every rank runs the same per-GPU workload on its own
+(batch x head) shard -- weak scaling, no collective on the timed path.  Rank 0 prints ONE JSON line:
 
   metric / value   whole-job attention-forward TFLOP/s (4*B*H*N^2*d flops per pass per GPU),
                    inputs resident in HBM, max-over-ranks wall time between barriers
@@ -144,12 +147,19 @@ def bench_config5_strong(mfa, rank, world, use_dist, steps=4, warm=2):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     assert bool(torch.isfinite(out[0, 0].float()).all())
+    heads_by_rank = [hi - lo]
+    if use_dist:
+        hb = torch.zeros(world, dtype=torch.int32, device="cuda")
+        hb[rank] = hi - lo
+        dist.all_reduce(hb)
+        heads_by_rank = hb.tolist()
+    assert sum(heads_by_rank) == B * H
     total = attn_flops(B, H, N, d)
     tf = total * steps / wall / 1e12
     del q, k, v, out
     torch.cuda.empty_cache()
     return {"workload": f"bf16 B={B} H={H} N={N} d={d}, one problem split by (batch x head) over {world} rank(s)",
-            "scaling": "strong", "heads_total": B * H, "heads_this_rank": hi - lo, "steps": steps,
+            "scaling": "strong", "heads_total": B * H, "heads_this_rank": hi - lo, "heads_by_rank": heads_by_rank, "steps": steps,
             "ms_per_pass": round(wall / steps * 1e3, 3), "TFLOP/s": round(tf, 1),
             "frac_mfma_peak_per_gpu": round(tf / world / MFMA_PEAK_TFLOPS, 4), "flops_per_pass": total}
 
@@ -413,6 +423,65 @@ def cpu_config1():
             "naive_attention_GFLOP/s": round(4 * 128 * 128 * 64 / t_a / 1e9, 2)}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run with N ranks of
+    this script as a CHILD process (this process has not touched the GPU and never will), pass
+    rank 0's one JSON line through and return the child's exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    log(f"[bench] --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith("{"):
+            log(ln)
+    if proc.returncode != 0:
+        log(f"[bench] the launcher exited with status {proc.returncode}")
+        return proc.returncode
+    if len(lines) != 1:
+        log(f"[bench] expected one JSON line from rank 0, got {len(lines)}")
+        return 1
+    got = json.loads(lines[0]).get("n_gpus")
+    if got != n:
+        log(f"[bench] the ranks report n_gpus={got}, asked for {n}")
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
+def stub_rank(args, world, rank):
+    """--stub: the launcher / rendezvous / one-line-JSON plumbing with no GPU in it (gloo, CPU
+    tensors, a token workload), so that the multi-rank path of this script is testable on a box
+    without GPUs.  Measures nothing: metric and data say so."""
+    dist.init_process_group("gloo")
+    ones = torch.ones(1)
+    dist.all_reduce(ones)
+    heads = torch.zeros(world, dtype=torch.int64)
+    from my_flash_attn_cuda import sharding   # loads the library (no GPU call), as every rank does
+    lo, hi = sharding.head_range(256, rank, world)
+    heads[rank] = hi - lo
+    dist.all_reduce(heads)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        torch.ones(64, 64) @ torch.ones(64, 64)
+    dist.barrier()
+    wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "stub (launcher self-test, nothing measured)", "value": 0.0, "unit": "none",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(float(wall.item()) / max(args.steps, 1) * 1e3, 4), "data": "stub",
+                          "verify": {"ranks": int(ones.item()), "heads_by_rank": heads.tolist()}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -426,13 +495,23 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the barriers / reductions / checksum gather "
                          "even with one rank (rehearsal of the multi-GPU path on a one-GPU box)")
+    ap.add_argument("--stub", action="store_true",
+                    help="launcher self-test: gloo, CPU tensors, a token workload; measures nothing")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.force_dist:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+        log(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report "
+            f"a {args.gpus}-GPU number measured on {world}")
+        sys.exit(2)
+    if args.stub:
+        return stub_rank(args, world, rank)
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     # Rank 0's stdout carries exactly one line, the JSON.  RCCL prints a version banner to the
@@ -465,6 +544,13 @@ def main():
     torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - tg) * 1e3
     assert bool(torch.isfinite(table).all()) and table.shape == (world * B * H, 2)
+    # what RCCL saw: an all-reduce of 1 over the ranks
+    ranks_seen = 1
+    if use_dist:
+        one = torch.ones(1, dtype=torch.int32, device="cuda")
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+        assert ranks_seen == world, f"all-reduce of 1 over the ranks gave {ranks_seen}, world is {world}"
     flops = attn_flops(B, H, N, d, args.causal)
     value = world * args.steps * flops / wall / 1e12
     achieved = flops / (mean_ms * 1e-3) / 1e12
@@ -498,12 +584,13 @@ def main():
                      # by this run: counters need rocprofv3); algorithmic bytes are 4*B*H*N*d*2
                      "traffic": traffic["bytes"] if traffic else None,
                      "traffic_detail": traffic, "algorithmic_bytes": 4.0 * B * H * N * d * 2,
-                     "kernel": "attn_fwd_mfma16_kernel" if not args.causal else "attn_fwd_mfma_pp_kernel",
+                     "kernel": mfa.attn_fwd_kernel_name(d, dtype, args.causal),
                      "launch_ms_mean": round(mean_ms, 4),
                      "launch_timing": "one HIP event pair around the K timed launches / K", "flops_per_launch": flops},
         "config5_strong_scaling": config5,
     }
-    result["verify"] = {"gathered_head_checksums": int(table.shape[0]), "gather_ms_untimed_path": round(gather_ms, 3)}
+    result["verify"] = {"ranks": ranks_seen, "gathered_head_checksums": int(table.shape[0]),
+                        "gather_ms_untimed_path": round(gather_ms, 3)}
     if rank == 0 and world == 1 and not args.no_extras and not args.causal:
         result["headline_scale_one"] = bench_shape(mfa, B, H, N, d, dtype, 1.0)
         result["config3"] = bench_shape(mfa, 8, 16, 1024, 64, torch.float16, 64 ** -0.5, iters=100)

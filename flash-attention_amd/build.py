@@ -52,10 +52,15 @@ def _newest_header():
 def _compile(src, extra, objdir=OBJ):
     obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
+    cmd = [_hipcc(), *FLAGS, *PER_SOURCE_FLAGS.get(src, []), *extra, "-c", path, "-o", obj]
+    # an object is reused only if it was built by the same command line from sources not newer than it
+    tag = obj + ".cmd"
     stamp = max(os.path.getmtime(path), _newest_header(), os.path.getmtime(__file__))
-    if os.path.exists(obj) and os.path.getmtime(obj) >= stamp:
+    if os.path.exists(obj) and os.path.getmtime(obj) >= stamp and os.path.exists(tag) and open(tag).read() == " ".join(cmd):
         return obj, False
-    subprocess.check_call([_hipcc(), *FLAGS, *PER_SOURCE_FLAGS.get(src, []), *extra, "-c", path, "-o", obj])
+    subprocess.check_call(cmd)
+    with open(tag, "w") as f:
+        f.write(" ".join(cmd))
     return obj, True
 
 
@@ -86,5 +91,16 @@ def build_library(force=False, verbose=True, extra_flags=(), tuning=True):
     return lib
 
 
+def build_experiment(name, flags, verbose=True):
+    """A tuning-flavour build with extra -D flags, for A/B runs of compile-time variants in one
+    process (tools/ab_attn.py `lib=` specs): my_flash_attn_cuda/exp_<name>.so.  Not shipped."""
+    lib = os.path.join(PKG, f"exp_{name}.so")
+    return _build_one(lib, OBJ + "_exp_" + name, ["-DMYFA_TUNING", *flags], False, verbose)
+
+
 if __name__ == "__main__":
-    build_library(force="--force" in sys.argv)
+    if "--exp" in sys.argv:
+        i = sys.argv.index("--exp")
+        build_experiment(sys.argv[i + 1], sys.argv[i + 2:])
+    else:
+        build_library(force="--force" in sys.argv)

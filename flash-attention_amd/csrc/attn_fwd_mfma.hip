@@ -695,7 +695,7 @@ int launch(const void* q, const void* k, const void* v, void* o, float* lse,
         auto go = [&](auto kern) {
             launch_kernel(kern, dim3((unsigned)nwg), dim3(kThreads), 0, s,
                                static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
-                               static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, tn.attn_thr, (int)d, tn.attn_dbg);
+                               static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, tn.attn_thr < 0.f ? 8.f : tn.attn_thr, (int)d, tn.attn_dbg);
         };
 #ifdef MYFA_TUNING
         if (causal && tn.attn_dbg != nullptr) go(attn_fwd_mfma_pp_kernel<T, D, true, true>);
@@ -711,9 +711,19 @@ int launch(const void* q, const void* k, const void* v, void* o, float* lse,
 }  // namespace
 
 int attn_fwd_mfma16(const void* q, const void* k, const void* v, void* o, float* lse,
-                    int64_t heads, int64_t N, int64_t d, float scale, float thr, int dtype, bool causal, hipStream_t s);
+                    int64_t heads, int64_t N, int64_t d, float scale, float thr, int spec, int xflags,
+                    int dtype, bool causal, hipStream_t s);
 int attn_fwd_mfma_wide(const void* q, const void* k, const void* v, void* o, float* lse,
                        int64_t heads, int64_t N, int64_t d, float scale, float thr, int dtype, bool causal, hipStream_t s);
+
+// The kernel the dispatch below picks (kept beside it so that the two cannot drift apart).
+const char* attn_fwd_mfma_kernel_name(int64_t d, [[maybe_unused]] int dtype, [[maybe_unused]] bool causal) {
+    if (d < 8 || d > 256 || d % 8 != 0) return nullptr;
+    if (d > 128) return "attn_fwd_mfma_wide_kernel";
+    const int variant = tuning().attn_variant;
+    if (variant == 2 || variant < 0) return "attn_fwd_mfma16_kernel";
+    return variant == 0 && !causal && (d == 64 || d == 128) ? "attn_fwd_mfma_kernel" : "attn_fwd_mfma_pp_kernel";
+}
 
 // dtype: MYFA_F16 or MYFA_BF16; d: a multiple of 8 in 8..256; heads = B*H
 int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* lse,
@@ -725,10 +735,12 @@ int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* l
     // its tile loop is split in two, unmasked tiles in front of the workgroup's rows and the masked
     // tiles on the diagonal, so the first loop is the unmasked kernel's code: even with the 32x32x16
     // build at d = 128 (N = 4096; +1 % at N = 16384) and +32..38 % at d = 64.
-    if (d > 128) return attn_fwd_mfma_wide(q, k, v, o, lse, heads, N, d, scale, tuning().attn_thr, dtype, causal, s);
+    const float thr_classic = tuning().attn_thr < 0.f ? 8.f : tuning().attn_thr;
+    if (d > 128) return attn_fwd_mfma_wide(q, k, v, o, lse, heads, N, d, scale, thr_classic, dtype, causal, s);
     const int variant = tuning().attn_variant;
     if (variant == 2 || variant < 0)
-        return attn_fwd_mfma16(q, k, v, o, lse, heads, N, d, scale, tuning().attn_thr, dtype, causal, s);
+        return attn_fwd_mfma16(q, k, v, o, lse, heads, N, d, scale, tuning().attn_thr, tuning().attn_spec,
+                               tuning().attn_xflags, dtype, causal, s);
     // head dims that are multiples of 8 run on the next build up, the missing columns read as zeros
     if (d >= 8 && d <= 128 && d % 8 == 0) {
         const bool big = d > 64;

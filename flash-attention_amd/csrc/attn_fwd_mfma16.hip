@@ -31,6 +31,7 @@
 // g in {0,1} or {2,3}: rows that differ by 4 get different 32-byte halves), and every fragment
 // address is one of three per-lane bases plus an immediate.
 #include "attn_mfma_common.h"
+#include "tuning.h"
 
 namespace myfa {
 namespace {
@@ -84,11 +85,34 @@ constexpr int kBKV16 = 64;             // keys per tile
 // added to it cannot wrap: fetches from there read zero without touching memory.
 constexpr int kPastEnd = 0x7FFF0000;
 
-template <typename T, int D, bool CAUSAL = false>
+// SPEC = true: the running max is not looked for in every tile.  The weights of a tile are formed
+// against the running max as it stands, and only when a lane's partial row sum passes `thr` (a
+// limit `lim` = 2^thr: some weight then reached 2^(thr-4)) does the wave go back, find
+// the tile's row maxima, move the running max, rescale O and l and form the weights again from the
+// logits, which are still in their registers.  (The first tile and the masked tiles on the diagonal
+// of a causal launch take the other path.)  16 v_max3, the exchange between the four lanes of
+// a row and the vote leave the common path: a quarter of the vector phase's issue slots, and it is
+// the vector issue port that bounds the loop.  The result is what the deferred max gives (weights
+// up to the limit instead of 1, the same relative rounding); SPEC = false keeps the vote on the
+// tile maxima (thr in log2 units; 0 = the textbook recurrence).
+// STAMP builds are diagnostic only (tuning flavour): they bracket the phases with s_memtime and
+// write the per-phase cycle sums of waves 0 and 4 to `dbg` (24 u64 per workgroup); never timed.
+__device__ __forceinline__ unsigned long long stamp16() {
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+template <typename T, int D, bool CAUSAL = false, bool SPEC = true, bool STAMP = false>
 __global__ void __launch_bounds__(kThreads16, D == 64 ? 4 : 2)
 attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* __restrict__ Vg,
                        T* __restrict__ Og, float* __restrict__ LSEg, int N, int nqblk, int nwg,
-                       float sl2, float thr, int gd) {
+                       float sl2, float thr, float lim, int gd, [[maybe_unused]] int probe,
+                       [[maybe_unused]] unsigned long long* __restrict__ dbg) {
+    [[maybe_unused]] unsigned long long t_k0 = 0, t_l0 = 0, t_l1 = 0, cyc[6] = {0, 0, 0, 0, 0, 0};
+    if constexpr (STAMP) t_k0 = stamp16();
     using M = Mma16<T>;
     using vec8 = typename M::vec8;
     using vec4 = typename M::vec4;
@@ -258,7 +282,12 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
     auto nothing = [](int) __attribute__((always_inline)) {};
 
     // MASK = false: a tile that lies before every row of the workgroup and inside N (causal builds
-    // run those tiles in a loop of their own, whose code then is the code of the unmasked kernel)
+    // run those tiles in a loop of their own, whose code then is the code of the unmasked kernel).
+    // The workgroup's first tile needs nothing special: against a running max of -inf every weight
+    // and with it every row sum is infinite (or NaN where the logit is masked), which sends the
+    // speculative path back and trips the other path's vote, and O and l are still zero when they
+    // are scaled by exp2(-inf) = 0.  (A first tile with code of its own, no rescale in it, was
+    // tried: the causal builds then spill 23-55 vector registers in their masked loop.)
     auto softmax = [&](int kv0, auto mask_flag) __attribute__((always_inline)) {
         constexpr bool MASK = decltype(mask_flag)::value != 0;
         // keys past N, and under the causal mask keys after the lane's query rows; a tile the
@@ -277,33 +306,20 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
         // row max: four independent chains of v_max3_f32 (two per query), written out as single
         // instructions (vmax3 / vmax2: fmaxf would first quiet a possible signalling NaN in every
         // chain head, and one serial chain per query costs its latency 16 times over)
-        float tmax[2];
+        auto lane_max = [&](float (&tmax)[2]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            float a = vmax3(s[0][qb][0], s[0][qb][1], s[0][qb][2]);
-            float b = vmax3(s[2][qb][0], s[2][qb][1], s[2][qb][2]);
-            a = vmax3(a, s[0][qb][3], s[1][qb][0]);
-            b = vmax3(b, s[2][qb][3], s[3][qb][0]);
-            a = vmax3(a, s[1][qb][1], s[1][qb][2]);
-            b = vmax3(b, s[3][qb][1], s[3][qb][2]);
-            tmax[qb] = vmax3(a, b, vmax2(s[1][qb][3], s[3][qb][3]));
-        }
-        // A row's max passes the threshold exactly when one of its four lanes' partial maxima does,
-        // so the lanes can vote on their own 16 logits and leave the exchange between the four lanes
-        // of a row to the (rare) tile in which the running max has to move: 12 instructions fewer per
-        // tile.  Measured: at D = 64, where the vector issue port is the bound, that is what it saves;
-        // at D = 128 the kernel takes 3.6 % MORE cycles with it (the compiler's schedule of the phase
-        // changes), so there the exchange stays in front of the vote.
-        constexpr bool LAZY = D == 64;
-        Pair mt_ = {tmax[0], tmax[1]};
-        if constexpr (!LAZY) mt_ = four_row_reduce(tmax[0], tmax[1], RawMaxOp{});
-        float mt[2] = {mt_.a * sl2, mt_.b * sl2};
-        if (__builtin_amdgcn_ballot_w64((mt[0] - m[0] > thr) || (mt[1] - m[1] > thr)) != 0) {   // wave-uniform
-            if constexpr (LAZY) {
-                mt_ = four_row_reduce(tmax[0], tmax[1], RawMaxOp{});
-                mt[0] = mt_.a * sl2;
-                mt[1] = mt_.b * sl2;
+            for (int qb = 0; qb < 2; ++qb) {
+                float a = vmax3(s[0][qb][0], s[0][qb][1], s[0][qb][2]);
+                float b = vmax3(s[2][qb][0], s[2][qb][1], s[2][qb][2]);
+                a = vmax3(a, s[0][qb][3], s[1][qb][0]);
+                b = vmax3(b, s[2][qb][3], s[3][qb][0]);
+                a = vmax3(a, s[1][qb][1], s[1][qb][2]);
+                b = vmax3(b, s[3][qb][1], s[3][qb][2]);
+                tmax[qb] = vmax3(a, b, vmax2(s[1][qb][3], s[3][qb][3]));
             }
+        };
+        // the running max moves to max(m, tile max); O and l follow
+        auto move_max = [&](const float (&mt)[2]) __attribute__((always_inline)) {
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 const float m_new = fmaxf(m[qb], mt[qb]);
@@ -315,29 +331,85 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[db][qb][r] *= alpha;
             }
-        }
+        };
+        // Only the tiles of a loop without mask code are speculated on: behind the mask code the
+        // logits would have to stay alive beside the weights, and those few tiles (the diagonal
+        // under the causal mask) then spill registers.
+        constexpr bool SPECULATE = SPEC && !(CAUSAL && MASK);
+        float psum[2];
+        f32x4 p_[SPECULATE ? 4 : 1][2];
+        auto& p = [&]() __attribute__((always_inline)) -> auto& { if constexpr (SPECULATE) return p_; else return s; }();
         // (Measured on this block: the same instructions in the compiler's order -- per query four
         // (scale-subtract, exp2) pairs, then (scale-subtract, add, exp2) triples -- run the kernel in
         // 7 % fewer cycles than either the two queries interleaved or any order pinned with
         // sched_group_barrier or written as one asm statement, which costs register copies.)
+        auto weights = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            float psum = 0.f;
+            for (int qb = 0; qb < 2; ++qb) {
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+                for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    s[kb][qb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][qb][r], sl2, -m[qb]));
-                    psum += s[kb][qb][r];
+                    for (int r = 0; r < 4; ++r) {
+                        p[kb][qb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][qb][r], sl2, -m[qb]));
+                        if (kb == 0 && r == 0) psum[qb] = p[kb][qb][r];
+                        else psum[qb] += p[kb][qb][r];
+                    }
+            }
+        };
+        if constexpr (SPECULATE) {
+            weights();
+            // negated comparisons: a NaN or an infinite sum goes back too
+            if (__builtin_amdgcn_ballot_w64(!(psum[0] <= lim) || !(psum[1] <= lim)) != 0) {   // wave-uniform
+                float tmax[2];
+                lane_max(tmax);
+                const Pair mt_ = four_row_reduce(tmax[0], tmax[1], RawMaxOp{});
+                const float mt[2] = {mt_.a * sl2, mt_.b * sl2};
+                move_max(mt);
+                weights();
+            }
+        } else {
+            float tmax[2];
+            lane_max(tmax);
+            // A row's max passes the threshold exactly when one of its four lanes' partial maxima does,
+            // so the lanes can vote on their own 16 logits and leave the exchange between the four lanes
+            // of a row to the (rare) tile in which the running max has to move: 12 instructions fewer per
+            // tile.  Measured: at D = 64, where the vector issue port is the bound, that is what it saves;
+            // at D = 128 the kernel takes 3.6 % MORE cycles with it (the compiler's schedule of the phase
+            // changes), so there the exchange stays in front of the vote.
+            constexpr bool LAZY = D == 64;
+            Pair mt_ = {tmax[0], tmax[1]};
+            if constexpr (!LAZY) mt_ = four_row_reduce(tmax[0], tmax[1], RawMaxOp{});
+            float mt[2] = {mt_.a * sl2, mt_.b * sl2};
+            if (__builtin_amdgcn_ballot_w64((mt[0] - m[0] > thr) || (mt[1] - m[1] > thr)) != 0) {   // wave-uniform
+                if constexpr (LAZY) {
+                    mt_ = four_row_reduce(tmax[0], tmax[1], RawMaxOp{});
+                    mt[0] = mt_.a * sl2;
+                    mt[1] = mt_.b * sl2;
                 }
-            l[qb] += psum;
+                move_max(mt);
+            }
+            weights();
         }
+        l[0] += psum[0];
+        l[1] += psum[1];
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pb[st][qb][j] = (T)s[2 * st + (j >> 2)][qb][j & 3];
+                for (int j = 0; j < 8; ++j) pb[st][qb][j] = (T)p[2 * st + (j >> 2)][qb][j & 3];
+        // The conversions belong to the vector phase: left alone, the compiler sinks them (and the two
+        // additions to l) below the phase barrier, in front of the matrix phase's first MFMA -- 80
+        // cycles at the head of the phase that is the critical path.  Pinned here: +3.3 % (D = 128).
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                u32x4 w = __builtin_bit_cast(u32x4, pb[st][qb]);
+                asm volatile("" : "+v"(w));
+                pb[st][qb] = __builtin_bit_cast(vec8, w);
+            }
+        asm volatile("" : "+v"(l[0]), "+v"(l[1]));
     };
 
     // key tiles of this workgroup (causal: up to the block's last row; the first tile always
@@ -402,6 +474,8 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
     // fragment request, and every wave waits for its own at the end of its X(t+1).
     int k1 = 1, v0 = 0;              // (t+1) % 4, t % 3
     auto tile_step = [&](int t, auto mask_flag) __attribute__((always_inline)) {
+        [[maybe_unused]] unsigned long long ta = 0, tb = 0, tc = 0, tx = 0, td = 0, te = 0;
+        if constexpr (STAMP) ta = stamp16();
         const int k2 = (k1 + 1) & 3;             // (t+2) % 4
         const int k3 = (k1 + 2) & 3;             // (t+3) % 4
         const int v1 = v0 == 2 ? 0 : v0 + 1;     // (t+1) % 3
@@ -411,25 +485,40 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
             constexpr int L0 = NQ + NP - FW;     // no fragment requests from here on
 #pragma unroll
             for (int j = 0; j < LPT; ++j) {
+                if constexpr (STAMP) { if (probe & 8) continue; }   // timing probe: no fetches (wrong results)
                 if (i == L0 + 2 * j)     fetch_piece(krs, t + 3, k3 * TILE_B, j);
                 if (i == L0 + 2 * j + 1) fetch_piece(vrs, t + 2, (4 + v2) * TILE_B, j);
             }
         });
+        if constexpr (STAMP) tb = stamp16();
         phase_barrier();                         // the fetches just issued stay in flight across it
+        if constexpr (STAMP) tc = stamp16();
         // ---- X(t+1)
-        softmax((t + 1) * kBKV16, mask_flag);
+        if constexpr (STAMP) {   // timing probe: no vector phase (wrong results)
+            if (!(probe & 16)) softmax((t + 1) * kBKV16, mask_flag);
+        } else {
+            softmax((t + 1) * kBKV16, mask_flag);
+        }
+        if constexpr (STAMP) tx = stamp16();
         dma_wait();                              // this wave's share of K(t+3), V(t+2) is in LDS
         prefill(k2, v1, IC<0>{}, IC<NQ + NP>{}); // first fragments of M(t+1): K(t+2)
+        if constexpr (STAMP) td = stamp16();
         phase_barrier();
+        if constexpr (STAMP) {
+            te = stamp16();
+            cyc[0] += tb - ta; cyc[1] += tc - tb; cyc[2] += tx - tc; cyc[3] += td - tx; cyc[4] += te - td;
+        }
         k1 = k2; v0 = v1;
     };
     int t = 0;
+    if constexpr (STAMP) t_l0 = stamp16();
     if constexpr (CAUSAL) {
         // tiles 1 .. t_clean-1 lie before the workgroup's first row and inside N: no mask code
         const int t_clean = min(q0, N) / kBKV16;
         for (; t + 1 < min(T_, t_clean); ++t) tile_step(t, IC<0>{});
     }
     for (; t + 1 < T_; ++t) tile_step(t, IC<1>{});
+    if constexpr (STAMP) t_l1 = stamp16();
     prefill(0, v0, IC<NQ>{}, IC<NQ + NP>{});
     mma_stream(0, v0, IC<NQ>{}, IC<NQ + NP>{}, nothing);   // M(T-1): O += V(T-1)^T P^T
     dma_wait();
@@ -471,38 +560,81 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
             if (qr < N) LSEg[(size_t)head * N + qr] = (mm + __builtin_amdgcn_logf(ll)) * 0.6931471805599453f;
         }
     }
+    if constexpr (STAMP) {
+        if (dbg != nullptr && (wave == 0 || wave == 4) && lane == 0) {
+            unsigned long long* o_ = dbg + (size_t)blockIdx.x * 24 + (wave >> 2) * 12;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) o_[i] = cyc[i];
+            o_[5] = t_l0 - t_k0;
+            o_[6] = stamp16() - t_l1;
+            o_[7] = T_;
+        }
+    }
 }
 
 template <typename T, int D>
 int launch16(const void* q, const void* k, const void* v, void* o, float* lse,
-             int64_t heads, int64_t N, int64_t d, float scale, float thr, bool causal, hipStream_t s) {
+             int64_t heads, int64_t N, int64_t d, float scale, float thr, bool spec, int probe, bool causal, hipStream_t s) {
     if (N * d * 2 >= (int64_t)kPastEnd) return fail(MYFA_E_UNSUPPORTED, "attention: N*d=%lld per head too large", (long long)(N * d));
     const int64_t nqblk = cdiv(N, kBQ16);
     const int64_t nwg = heads * nqblk;
     if (nwg > 0x7fffffffLL) return fail(MYFA_E_UNSUPPORTED, "attention: too many workgroups (%lld)", (long long)nwg);
     const float sl2 = scale * 1.4426950408889634f;
-    auto go = [&](auto kern) {
+    const float lim = exp2f(thr);   // the speculative path compares row sums, not logits
+    [[maybe_unused]] unsigned long long* dbg = tuning().attn_dbg;
+    auto go = [&](auto kern, unsigned long long* dbg_) {
         launch_kernel(kern, dim3((unsigned)nwg), dim3(kThreads16), 0, s,
                            static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
-                           static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, thr, (int)d);
+                           static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, thr, lim, (int)d, probe, dbg_);
     };
-    if (causal) go(attn_fwd_mfma16_kernel<T, D, true>);
-    else go(attn_fwd_mfma16_kernel<T, D, false>);
+#ifdef MYFA_TUNING
+    if (dbg != nullptr && D == 128 && !causal) {
+        if (spec) go(attn_fwd_mfma16_kernel<T, 128, false, true, true>, dbg);
+        else go(attn_fwd_mfma16_kernel<T, 128, false, false, true>, dbg);
+        return check_launch("attn_fwd_mfma16 (stamped)");
+    }
+#endif
+    // Under the causal mask the speculative form loses (941 against 1004 TFLOP/s at the headline shape,
+    // 726 against 777 at d = 64: the masked tiles take the other path anyway and the build carries both).
+    if (causal) go(attn_fwd_mfma16_kernel<T, D, true, false>, nullptr);
+    else if (spec) go(attn_fwd_mfma16_kernel<T, D, false, true>, nullptr);
+    else go(attn_fwd_mfma16_kernel<T, D, false, false>, nullptr);
     return check_launch("attn_fwd_mfma16");
 }
 
 }  // namespace
 
-// dtype: MYFA_F16 or MYFA_BF16; d: 64 or 128; heads = B*H; thr: deferred-max threshold (log2 units)
+// dtype: MYFA_F16 or MYFA_BF16; d: a multiple of 8 in 8..128; heads = B*H.
+//
+// spec: 1 = the speculative build, 0 = the build that votes on the tile maxima, < 0 = the library's
+// choice, which goes by how peaked the softmax of unit-variance inputs would be: their logits have a
+// standard deviation of scale * log2(e) * sqrt(d) in base-2 units -- 1.44 at scale = d^-1/2, 16.3
+// with the reference's unscaled logits at d = 128 (tests/test_flash_attn.py:165).  Up to 4 the
+// speculative build runs (+3..4 % at d = 128, +7..10 % at d = 64; rows are sums of many comparable
+// weights, and a stale max costs no accuracy: max |error| 1.6e-3 in bfloat16 at any limit).  Beyond,
+// a row is usually one dominant key, the running max has to move in a third of the tiles, and what
+// a stale max costs there is accuracy: the dominant key's weight is then some 2^x instead of the
+// exactly representable 1, its rounding (relative 2^-8 in bfloat16) no longer cancels against the
+// float32 row sum, and |error| reaches 0.031 (4 elements in 12.6 million above 2e-2 with the vote
+// at thr = 8, 15 with a limit of 2^30; none at thr = 0, where the bound is the output's own
+// rounding, 0.0156 for |O| in [4, 8)).  There the vote at thr = 8 runs, as before.
+// thr < 0: the library's choice: 8 for the vote; for the speculative build a lane's partial row sum
+// may reach 2^12 with float16 weights (largest finite value 65504) and 2^30 with bfloat16 weights,
+// which have float32's exponent range.
 int attn_fwd_mfma16(const void* q, const void* k, const void* v, void* o, float* lse,
-                    int64_t heads, int64_t N, int64_t d, float scale, float thr, int dtype, bool causal, hipStream_t s) {
+                    int64_t heads, int64_t N, int64_t d, float scale, float thr, int spec, int probe,
+                    int dtype, bool causal, hipStream_t s) {
+    const bool sp = spec < 0 ? scale * 1.4426950408889634f * sqrtf((float)d) <= 4.0f : spec != 0;
+    if (thr < 0.f) thr = !sp || causal ? 8.f : dtype == MYFA_BF16 ? 30.f : 12.f;
+    if (dtype == MYFA_F16 && thr > 15.f) thr = 15.f;
+    if (thr > 60.f) thr = 60.f;
     // head dims that are multiples of 8 run on the next build up, the missing columns read as zeros
     if (d >= 8 && d <= 128 && d % 8 == 0) {
         const bool big = d > 64;
-        if (dtype == MYFA_BF16) return big ? launch16<__bf16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s)
-                                           : launch16<__bf16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s);
-        if (dtype == MYFA_F16)  return big ? launch16<_Float16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s)
-                                           : launch16<_Float16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s);
+        if (dtype == MYFA_BF16) return big ? launch16<__bf16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, sp, probe, causal, s)
+                                           : launch16<__bf16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, sp, probe, causal, s);
+        if (dtype == MYFA_F16)  return big ? launch16<_Float16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, sp, probe, causal, s)
+                                           : launch16<_Float16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, sp, probe, causal, s);
     }
     return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16): head dim %lld is not a multiple of 8 in 8..128", (long long)d);
 }

@@ -55,6 +55,7 @@ int attn_fwd_f32(const float* q, const float* k, const float* v, float* o, float
 size_t attn_fwd_f32_ws_bytes(int64_t heads, int64_t N, int64_t d);
 int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* lse,
                   int64_t heads, int64_t N, int64_t d, float scale, int dtype, bool causal, hipStream_t s);
+const char* attn_fwd_mfma_kernel_name(int64_t d, int dtype, bool causal);
 int attn_bwd_mfma(const void* q, const void* k, const void* v, const void* o, const float* lse, const void* dout,
                   void* dq, void* dk, void* dv, float* delta, int64_t heads, int64_t N, int64_t d,
                   float scale, int dtype, bool causal, hipStream_t s);
@@ -175,6 +176,13 @@ int myfa_attn_fwd_bhnd_ex(const void* q, const void* k, const void* v, void* o, 
     }
 }
 
+const char* myfa_attn_fwd_bhnd_kernel(int64_t d, int dtype, int flags) {
+    if ((flags & ~MYFA_ATTN_CAUSAL) != 0 || d <= 0) return nullptr;
+    if (dtype == MYFA_F32) return d <= 512 ? "attn_fwd_f32_kernel" : nullptr;
+    if (dtype != MYFA_F16 && dtype != MYFA_BF16) return nullptr;
+    return attn_fwd_mfma_kernel_name(d, dtype, (flags & MYFA_ATTN_CAUSAL) != 0);
+}
+
 int myfa_attn_bwd_bhnd(const void* q, const void* k, const void* v, const void* o, const float* lse,
                        const void* dout, void* dq, void* dk, void* dv, float* delta_ws,
                        int64_t B, int64_t H, int64_t N, int64_t d, float scale, int dtype, int flags, void* stream) {
@@ -231,6 +239,8 @@ int myfa_tuning_set(const char* key, double value) {
     if (k == "reset") t = Tuning{};
     else if (k == "attn_variant") t.attn_variant = (int)value;
     else if (k == "attn_thr") t.attn_thr = (float)value;
+    else if (k == "attn_spec") t.attn_spec = (int)value;
+    else if (k == "attn_xflags") t.attn_xflags = (int)value;
     else if (k == "attn_bq") t.attn_bq = (int)value;
     else if (k == "attn_f32_wgs") t.attn_f32_wgs = (int)value;
     else if (k == "matmul_block") t.matmul_block = (int)value;

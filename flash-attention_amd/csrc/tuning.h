@@ -18,8 +18,15 @@ struct Tuning {
     //   2 = 16x16x32 MFMA, same schedule as 1
     //  -1 = the library's choice per shape
     int attn_variant = -1;
-    // deferred-max threshold in log2 units (0 = rescale whenever a row max grows: the textbook recurrence)
-    float attn_thr = 8.f;
+    // deferred-max threshold in log2 units (0 = rescale whenever a row max grows: the textbook
+    // recurrence); < 0 = the library's choice per kernel and element type
+    float attn_thr = -1.f;
+    // 16x16x32 build: 1 = weights formed against the standing max, the max looked for only when a row
+    // sum passes 2^attn_thr; 0 = the max of every tile, vote on its growth; -1 = the library's choice
+    int attn_spec = -1;
+    // timing probes of the stamped 16x16x32 build (wrong results): 8 = no tile fetches in the loop,
+    // 16 = no vector phase
+    int attn_xflags = 0;
     // query rows per workgroup for the ping-pong kernels: 0 = library's choice, else 128 or 256
     int attn_bq = 0;
     // device buffer for the stamped (cycle-counting) diagnostic build, 24 u64 per workgroup

@@ -271,6 +271,13 @@ def flash_attn_fwd(q, k, v, scale=1.0, return_lse=False, causal=False):
     return (out, lse) if return_lse else out
 
 
+def attn_fwd_kernel_name(d, dtype, causal=False):
+    """Name of the device kernel flash_attn_fwd launches for this head dim and dtype (what a kernel
+    trace shows), or None where the C entry point would refuse the call."""
+    name = _lib.lib.myfa_attn_fwd_bhnd_kernel(int(d), _DTYPE_TAG[dtype], ATTN_CAUSAL if causal else 0)
+    return name.decode() if name else None
+
+
 def flash_attn_bwd(dout, q, k, v, out, lse, scale=1.0, causal=False):
     """Gradients (dq, dk, dv) of flash_attn_fwd for float16 / bfloat16 (B, H, N, d) tensors,
     d <= 128 (64 and 128 natively, smaller ones through zero-padded copies).  `out` and `lse` are the forward's results (return_lse=True), `dout` the

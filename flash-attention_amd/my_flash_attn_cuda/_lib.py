@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MYFA_LIBRARY") or os.path.join(_HERE, "libmyfa_gfx950.so")
 TUNING_LIB_PATH = os.path.join(_HERE, "libmyfa_gfx950_tuning.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MYFA_F32, MYFA_F16, MYFA_BF16 = 0, 1, 2
 
 # every symbol include/myfa.h declares
@@ -32,6 +32,7 @@ EXPORTS = (
     "myfa_attn_fwd_f32_ws",
     "myfa_attn_fwd_bhnd",
     "myfa_attn_fwd_bhnd_ex",
+    "myfa_attn_fwd_bhnd_kernel",
     "myfa_attn_bwd_bhnd",
     "myfa_attn_bwd_bhnd_static_ws",
     "myfa_matmul_f32",
@@ -74,6 +75,8 @@ def _load():
     lib.myfa_attn_fwd_bhnd.restype = ci
     lib.myfa_attn_fwd_bhnd_ex.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, ci, ci, vp]
     lib.myfa_attn_fwd_bhnd_ex.restype = ci
+    lib.myfa_attn_fwd_bhnd_kernel.argtypes = [i64, ci, ci]
+    lib.myfa_attn_fwd_bhnd_kernel.restype = ctypes.c_char_p
     lib.myfa_attn_bwd_bhnd.argtypes = [vp] * 10 + [i64, i64, i64, i64, f32, ci, ci, vp]
     lib.myfa_attn_bwd_bhnd.restype = ci
     lib.myfa_attn_bwd_bhnd_static_ws.argtypes = [vp] * 9 + [i64, i64, i64, i64, f32, ci, ci, vp]

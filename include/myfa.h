@@ -33,8 +33,9 @@ extern "C" {
 #endif
 
 /* 2: the entry points with a caller workspace or the library's own (…_ws, …_static_ws), the fused
- * softmax prologue (…_nd_ex) and 16-bit head dims up to 256 were added; nothing of version 1 changed. */
-#define MYFA_ABI_VERSION 2
+ * softmax prologue (…_nd_ex) and 16-bit head dims up to 256 were added; nothing of version 1 changed.
+ * 3: myfa_attn_fwd_bhnd_kernel added; nothing of version 2 changed. */
+#define MYFA_ABI_VERSION 3
 
 enum {
     MYFA_OK = 0,
@@ -203,6 +204,15 @@ int myfa_attn_fwd_bhnd(const void* q, const void* k, const void* v, void* o, flo
 int myfa_attn_fwd_bhnd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
                           int64_t B, int64_t H, int64_t N, int64_t d,
                           float scale, int dtype, int flags, void* stream);
+
+/*
+ * Name of the device kernel that myfa_attn_fwd_bhnd_ex launches for head dim `d`, `dtype` and
+ * `flags` (the function name a kernel trace of the call shows, without template arguments), or
+ * NULL where the call would return an error.  For harnesses that label a measurement with the
+ * kernel it timed; launches nothing.  No counterpart in the reference (its launcher's switch,
+ * csrc/my_flash_attn/softmax.cu:459-487, is not queryable).
+ */
+const char* myfa_attn_fwd_bhnd_kernel(int64_t d, int dtype, int flags);
 
 /*
  * Backward of myfa_attn_fwd_bhnd_ex for MYFA_F16 / MYFA_BF16, d in {64, 128}:

@@ -209,19 +209,26 @@ def test_bhnd_errors(mfa):
         mfa.flash_attn_fwd(q, q.half(), q)
 
 
-@pytest.mark.parametrize("dtype,d", [(torch.bfloat16, 128), (torch.float16, 64)])
-def test_rescale_branch_is_forced(mfa, dtype, d):
+@pytest.mark.parametrize("scaled", [False, True])
+@pytest.mark.parametrize("dtype,d", [(torch.bfloat16, 128), (torch.float16, 64), (torch.float16, 128), (torch.bfloat16, 64)])
+def test_rescale_branch_is_forced(mfa, dtype, d, scaled):
     """Online-softmax rescale: plant keys that raise single rows' max late in the sweep
-    (at chosen tiles), so exp(m_old - m_new) << 1 is exercised, not just ~1."""
+    (at chosen tiles), so exp(m_old - m_new) << 1 is exercised, not just ~1.  Unscaled logits run
+    the build that looks for every tile's max; at d^-0.5 the library runs the build that forms
+    the weights against the standing max and goes back when a row sum passes its limit (2^30 in
+    bfloat16, 2^12 in float16): the planted logits, 4 |q|^2 d^-0.5 log2(e) = 46 (d = 64) or 65
+    (d = 128) base-2 units above the rest, send it back at the chosen tiles."""
     torch.manual_seed(1)
     N = 640
+    scale = d ** -0.5 if scaled else 1.0
     q, k, v = (torch.randn(1, 1, N, d) for _ in range(3))
     for row, key in [(0, 130), (5, 639), (31, 64), (32, 65), (100, 300), (255, 575), (256, 1), (639, 638)]:
-        k[0, 0, key] = q[0, 0, row] * 3.0          # logit ~ 3 |q|^2 >> the rest
+        k[0, 0, key] = q[0, 0, row] * (4.0 if scaled else 3.0)          # logit ~ 3 |q|^2 >> the rest
     qd, kd, vd = (x.cuda().to(dtype) for x in (q, k, v))
-    out = mfa.flash_attn_fwd(qd, kd, vd, scale=1.0)
-    ref = ref_cpu.attention_bhnd(_rounded(q, dtype), _rounded(k, dtype), _rounded(v, dtype), scale=1.0)
-    assert _maxdiff(out.float().cpu().numpy(), ref) <= LP_ATOL
+    out, lse = mfa.flash_attn_fwd(qd, kd, vd, scale=scale, return_lse=True)
+    qr, kr, vr = _rounded(q, dtype), _rounded(k, dtype), _rounded(v, dtype)
+    assert _maxdiff(out.float().cpu().numpy(), ref_cpu.attention_bhnd(qr, kr, vr, scale=scale)) <= LP_ATOL
+    assert _maxdiff(lse.cpu().numpy(), ref_cpu.attention_lse(qr, kr, scale=scale)) <= 2e-3
 
 
 def _sampled_check(mfa, c_oracle, B, H, N, d, dtype, scale, heads, nrows, seed=1):
