@@ -23,17 +23,18 @@ PKG = os.path.join(HERE, "my_flash_attn_cuda")
 LIB = os.path.join(PKG, "libmyfa_gfx950.so")
 # The same sources with -DMYFA_TUNING: launch knobs settable at run time through two extra
 # exported functions (csrc/tuning.h).  For tools/ and the tests that compare kernel variants;
-# the package never loads it unless MYFA_LIBRARY names it.
+# the package never loads it.
 LIB_TUNING = os.path.join(PKG, "libmyfa_gfx950_tuning.so")
 
 SOURCES = ["c_abi.hip", "softmax_rows.hip", "softmax_strided.hip", "attn_fwd_f32.hip", "attn_fwd_mfma.hip",
-           "attn_fwd_mfma16.hip", "attn_fwd_mfma256.hip", "attn_bwd_mfma.hip", "matmul_f32.hip"]
+           "attn_fwd_mfma16.hip", "attn_fwd_stream.hip", "attn_fwd_mfma256.hip", "attn_bwd_mfma.hip", "matmul_f32.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + INCLUDE, "-I" + CSRC,
          "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
 # The backward kernels place every vector instruction by hand between MFMAs; the SLP vectoriser
 # regroups them into packed float32 pairs with register shuffles around them.
-PER_SOURCE_FLAGS = {"attn_bwd_mfma.hip": ["-fno-slp-vectorize"], "attn_fwd_mfma16.hip": ["-fno-slp-vectorize"]}
+PER_SOURCE_FLAGS = {"attn_bwd_mfma.hip": ["-fno-slp-vectorize"], "attn_fwd_mfma16.hip": ["-fno-slp-vectorize"],
+                    "attn_fwd_stream.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():

@@ -662,12 +662,15 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     const T* dO = static_cast<const T*>(dout);
     const int64_t rows = heads * N;
     constexpr int RPB = 256 / (D / 8);
+    // every size check comes before the first launch: a launch status must not be left behind
+    // by an early return, to be reported against some later call of this thread
+    const int64_t nqblk = cdiv(N, 256), nkblk = cdiv(N, 128);
+    const int64_t nq = heads * nqblk, nk = heads * nkblk;
+    if (nq > 0x7fffffffLL || nk > 0x7fffffffLL || cdiv(rows, RPB) > 0x7fffffffLL)
+        return fail(MYFA_E_UNSUPPORTED, "attention backward: too many workgroups");
     launch_kernel((attn_bwd_delta_kernel<T, D>), dim3((unsigned)cdiv(rows, RPB)), dim3(256), 0, s, O, dO, lse, delta, (long long)rows);
     const float* lse2 = delta + rows;
 
-    const int64_t nqblk = cdiv(N, 256), nkblk = cdiv(N, 128);
-    const int64_t nq = heads * nqblk, nk = heads * nkblk;
-    if (nq > 0x7fffffffLL || nk > 0x7fffffffLL) return fail(MYFA_E_UNSUPPORTED, "attention backward: too many workgroups");
     if (causal) {
         launch_kernel((attn_bwd_dkv_kernel<T, D, true>), dim3((unsigned)nk), dim3(256), 0, s, Q, K, V, dO, lse2, delta,
                            static_cast<T*>(dk), static_cast<T*>(dv), (int)N, (int)nkblk, (int)nk, scale);

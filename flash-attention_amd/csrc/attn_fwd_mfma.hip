@@ -713,6 +713,9 @@ int launch(const void* q, const void* k, const void* v, void* o, float* lse,
 int attn_fwd_mfma16(const void* q, const void* k, const void* v, void* o, float* lse,
                     int64_t heads, int64_t N, int64_t d, float scale, float thr, int spec, int xflags,
                     int dtype, bool causal, hipStream_t s);
+int attn_fwd_stream(const void* q, const void* k, const void* v, void* o, float* lse,
+                    int64_t heads, int64_t N, int64_t d, float scale, float thr, int spec, int wgs,
+                    int dtype, bool causal, hipStream_t s);
 int attn_fwd_mfma_wide(const void* q, const void* k, const void* v, void* o, float* lse,
                        int64_t heads, int64_t N, int64_t d, float scale, float thr, int dtype, bool causal, hipStream_t s);
 
@@ -721,6 +724,7 @@ const char* attn_fwd_mfma_kernel_name(int64_t d, [[maybe_unused]] int dtype, [[m
     if (d < 8 || d > 256 || d % 8 != 0) return nullptr;
     if (d > 128) return "attn_fwd_mfma_wide_kernel";
     const int variant = tuning().attn_variant;
+    if (variant == 3 || (variant < 0 && d > 64)) return "attn_fwd_stream_kernel";
     if (variant == 2 || variant < 0) return "attn_fwd_mfma16_kernel";
     return variant == 0 && !causal && (d == 64 || d == 128) ? "attn_fwd_mfma_kernel" : "attn_fwd_mfma_pp_kernel";
 }
@@ -738,6 +742,13 @@ int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* l
     const float thr_classic = tuning().attn_thr < 0.f ? 8.f : tuning().attn_thr;
     if (d > 128) return attn_fwd_mfma_wide(q, k, v, o, lse, heads, N, d, scale, thr_classic, dtype, causal, s);
     const int variant = tuning().attn_variant;
+    // Head dims above 64: the resident-workgroup build (one workgroup per CU working through a list
+    // of query blocks as one unbroken stream of tiles: +4..5 % on random operands, +9.5 % in cycles
+    // over one workgroup per query block, whose fill and drain leave the CU's matrix cores idle for
+    // ~6 % of its life).  Up to 64 it still loses (register spills at 128 registers per lane).
+    if (variant == 3 || (variant < 0 && d > 64))
+        return attn_fwd_stream(q, k, v, o, lse, heads, N, d, scale, tuning().attn_thr, tuning().attn_spec,
+                               tuning().attn_wgs, dtype, causal, s);
     if (variant == 2 || variant < 0)
         return attn_fwd_mfma16(q, k, v, o, lse, heads, N, d, scale, tuning().attn_thr, tuning().attn_spec,
                                tuning().attn_xflags, dtype, causal, s);

@@ -36,47 +36,6 @@
 namespace myfa {
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <typename T> struct Mma16;
-template <> struct Mma16<__bf16> {
-    using vec8 = bf16x8;
-    using vec4 = bf16x4;
-    static __device__ __forceinline__ f32x4 run(s16x8 a, vec8 b, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vec8, a), b, c, 0, 0, 0);
-    }
-};
-template <> struct Mma16<_Float16> {
-    using vec8 = f16x8;
-    using vec4 = f16x4;
-    static __device__ __forceinline__ f32x4 run(s16x8 a, vec8 b, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vec8, a), b, c, 0, 0, 0);
-    }
-};
-
-// x0, x1: per-lane partial results for the lane's two queries (block 0, block 1), a query's
-// four partials sitting in lanes i, i+16, i+32, i+48.  Returns both totals in every lane.
-//   1. v_permlane32_swap(x0, x1) -> {x0.lo | x1.lo}, {x0.hi | x1.hi}; their combination holds
-//      x0 reduced over the two halves in lanes 0-31 and x1 likewise in lanes 32-63.
-//   2. v_permlane16_swap(c, c) -> {r0 r0 r2 r2}, {r1 r1 r3 r3} (16-lane rows of c); their
-//      combination is the total of x0 in rows 0,1 and the total of x1 in rows 2,3.
-//   3. v_permlane32_swap(e, e) -> {e.lo | e.lo}, {e.hi | e.hi}: both totals everywhere.
-struct Pair { float a, b; };
-template <class Op>
-__device__ __forceinline__ Pair four_row_reduce(float x0, float x1, Op op) {
-    const auto r1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x0), __builtin_bit_cast(unsigned, x1), false, false);
-    const unsigned a1 = r1[0], b1 = r1[1];
-    const float c = op(__builtin_bit_cast(float, a1), __builtin_bit_cast(float, b1));
-    const unsigned cu = __builtin_bit_cast(unsigned, c);
-    const auto r2 = __builtin_amdgcn_permlane16_swap(cu, cu, false, false);
-    const unsigned a2 = r2[0], b2 = r2[1];
-    const float e = op(__builtin_bit_cast(float, a2), __builtin_bit_cast(float, b2));
-    const unsigned eu = __builtin_bit_cast(unsigned, e);
-    const auto r3 = __builtin_amdgcn_permlane32_swap(eu, eu, false, false);
-    const unsigned a3 = r3[0], b3 = r3[1];
-    return {__builtin_bit_cast(float, a3), __builtin_bit_cast(float, b3)};
-}
-
 constexpr int kWaves16 = 8;
 constexpr int kThreads16 = kWaves16 * 64;
 constexpr int kBQ16 = kWaves16 * 32;   // query rows per workgroup

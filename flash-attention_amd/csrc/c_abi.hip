@@ -231,7 +231,7 @@ int myfa_matmul_f32(const float* a, const float* b, float* c, int64_t m, int64_t
 
 #ifdef MYFA_TUNING
 // Exported by the tuning flavour only (not part of include/myfa.h).  Keys: attn_variant,
-// attn_thr, attn_bq, matmul_block, matmul_ksplit, softmax_tpr, softmax_v, softmax_map, softmax_nt, softmax_pad,
+// attn_thr, attn_spec, attn_wgs, matmul_block, matmul_ksplit, softmax_tpr, softmax_v, softmax_map, softmax_nt, softmax_pad,
 // softmax_split_wgs, reset (back to the defaults).  Returns 0, or 1 for an unknown key.
 int myfa_tuning_set(const char* key, double value) {
     Tuning& t = tuning();
@@ -241,7 +241,7 @@ int myfa_tuning_set(const char* key, double value) {
     else if (k == "attn_thr") t.attn_thr = (float)value;
     else if (k == "attn_spec") t.attn_spec = (int)value;
     else if (k == "attn_xflags") t.attn_xflags = (int)value;
-    else if (k == "attn_bq") t.attn_bq = (int)value;
+    else if (k == "attn_wgs") t.attn_wgs = (int)value;
     else if (k == "attn_f32_wgs") t.attn_f32_wgs = (int)value;
     else if (k == "matmul_block") t.matmul_block = (int)value;
     else if (k == "matmul_ksplit") t.matmul_ksplit = (int)value;

@@ -271,6 +271,15 @@ int matmul_f32(const float* a, const float* b, float* c, int64_t m, int64_t k, i
     if (!c || ((!a || !b) && k > 0)) return fail(MYFA_E_INVALID, "matmul: null pointer");
     if (m > 0x7fffffffLL || k > 0x7fffffffLL || n > 0x7fffffffLL || cdiv(m, kBM) > 65535)
         return fail(MYFA_E_UNSUPPORTED, "matmul: size beyond the kernel's limits");
+    // c is written while a and b are still being read (and, with k split over two workgroups,
+    // cleared before anything is read): an output that shares storage with an input is refused
+    {
+        const uintptr_t c0 = reinterpret_cast<uintptr_t>(c), c1 = c0 + (size_t)m * (size_t)n * sizeof(float);
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(a), a1 = a0 + (size_t)m * (size_t)k * sizeof(float);
+        const uintptr_t b0 = reinterpret_cast<uintptr_t>(b), b1 = b0 + (size_t)k * (size_t)n * sizeof(float);
+        if (k > 0 && ((c0 < a1 && a0 < c1) || (c0 < b1 && b0 < c1)))
+            return fail(MYFA_E_INVALID, "matmul: the output overlaps an input (c may not alias a or b)");
+    }
     // (the vector path's 32-bit buffer offsets cover 128 rows of A and 16 rows of B)
     const bool vec = k % 4 == 0 && n % 4 == 0 && k <= (1 << 21) && n <= (1 << 24) &&
                      ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) % 16 == 0);

@@ -16,6 +16,7 @@ struct Tuning {
     //   0 = 32x32x16 MFMA, one barrier per tile, register-staged K/V
     //   1 = 32x32x16 MFMA, ping-pong of the two waves of a SIMD, LDS-DMA rings
     //   2 = 16x16x32 MFMA, same schedule as 1
+    //   3 = 16x16x32 MFMA, resident workgroups that stream through a list of query blocks
     //  -1 = the library's choice per shape
     int attn_variant = -1;
     // deferred-max threshold in log2 units (0 = rescale whenever a row max grows: the textbook
@@ -27,8 +28,8 @@ struct Tuning {
     // timing probes of the stamped 16x16x32 build (wrong results): 8 = no tile fetches in the loop,
     // 16 = no vector phase
     int attn_xflags = 0;
-    // query rows per workgroup for the ping-pong kernels: 0 = library's choice, else 128 or 256
-    int attn_bq = 0;
+    // resident-workgroup build: workgroups in the grid (0 = as many as the chip holds at once)
+    int attn_wgs = 0;
     // device buffer for the stamped (cycle-counting) diagnostic build, 24 u64 per workgroup
     unsigned long long* attn_dbg = nullptr;
     // float32 attention, keys split over workgroups: workgroup count the split aims at (0 = the default, 256)

@@ -278,6 +278,9 @@ def attn_fwd_kernel_name(d, dtype, causal=False):
     return name.decode() if name else None
 
 
+BWD_MAX_HEAD_DIM = 128
+
+
 def flash_attn_bwd(dout, q, k, v, out, lse, scale=1.0, causal=False):
     """Gradients (dq, dk, dv) of flash_attn_fwd for float16 / bfloat16 (B, H, N, d) tensors,
     d <= 128 (64 and 128 natively, smaller ones through zero-padded copies).  `out` and `lse` are the forward's results (return_lse=True), `dout` the
@@ -293,6 +296,9 @@ def flash_attn_bwd(dout, q, k, v, out, lse, scale=1.0, causal=False):
     if q.dtype not in (torch.float16, torch.bfloat16):
         raise RuntimeError(f"flash_attn_bwd supports float16 and bfloat16, got {q.dtype}")
     B, H, N, d = q.shape
+    if d > BWD_MAX_HEAD_DIM:
+        raise RuntimeError(f"flash_attn_bwd supports head dims up to {BWD_MAX_HEAD_DIM}, got {d} "
+                           "(the forward runs wider heads; their backward does not exist)")
     if lse.dtype != torch.float32 or tuple(lse.shape) != (B, H, N):
         raise RuntimeError("lse must be the float32 (B, H, N) tensor returned by flash_attn_fwd")
     if d not in (64, 128) and 0 < d < 128:
@@ -327,6 +333,9 @@ def flash_attn_bwd_into(dout, q, k, v, out, lse, dq, dk, dv, scale=1.0, causal=F
     if q.dtype not in (torch.float16, torch.bfloat16):
         raise RuntimeError(f"flash_attn_bwd supports float16 and bfloat16, got {q.dtype}")
     B, H, N, d = q.shape
+    if d not in (64, 128):
+        raise RuntimeError(f"flash_attn_bwd_into supports head dims 64 and 128, got {d} "
+                           "(flash_attn_bwd pads smaller ones through copies, which this entry may not make)")
     if lse.dtype != torch.float32 or tuple(lse.shape) != (B, H, N):
         raise RuntimeError("lse must be the float32 (B, H, N) tensor returned by flash_attn_fwd")
     with _on(q):
@@ -340,6 +349,9 @@ def flash_attn_bwd_into(dout, q, k, v, out, lse, dq, dk, dv, scale=1.0, causal=F
 class _FlashAttnFunc(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, scale, causal):
+        if q.dtype not in (torch.float16, torch.bfloat16) or q.shape[-1] > BWD_MAX_HEAD_DIM:
+            raise RuntimeError(f"flash_attn_func is differentiable for float16 / bfloat16 and head dims up to "
+                               f"{BWD_MAX_HEAD_DIM}; got {q.dtype}, d = {q.shape[-1]} (use flash_attn_fwd for inference)")
         out, lse = flash_attn_fwd(q, k, v, scale=scale, return_lse=True, causal=causal)
         ctx.save_for_backward(q, k, v, out, lse)
         ctx.scale, ctx.causal = scale, causal
@@ -353,7 +365,9 @@ class _FlashAttnFunc(torch.autograd.Function):
 
 
 def flash_attn_func(q, k, v, scale=1.0, causal=False):
-    """flash_attn_fwd with autograd support (float16 / bfloat16, d in {64, 128})."""
+    """flash_attn_fwd with autograd support: float16 / bfloat16, head dims up to 128 (64 and 128
+    natively, the others through zero-padded copies in the backward).  Wider heads and float32 have
+    a forward only and are refused here, before any work is done."""
     return _FlashAttnFunc.apply(q, k, v, scale, causal)
 
 
@@ -399,4 +413,6 @@ def my_matmul_out(out, A, B):
         raise RuntimeError("Size mismatch!")
     if not (out.dtype == A.dtype == B.dtype):
         raise RuntimeError("Scalar type mismatch!")
+    # `out` is written while A and B are being read: an output that shares storage with an input
+    # is refused (the C entry point checks the address ranges and its message surfaces here)
     return _matmul_into(out, A, B)

@@ -8,9 +8,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# MYFA_LIBRARY names another build of the same ABI (tools/ use it to load the tuning flavour,
-# libmyfa_gfx950_tuning.so); the ABI version check below applies to it all the same.
-LIB_PATH = os.environ.get("MYFA_LIBRARY") or os.path.join(_HERE, "libmyfa_gfx950.so")
+# The package loads exactly this file and reads no environment variable; tools/ and the variant
+# tests load the tuning flavour (TUNING_LIB_PATH) themselves, through tools/tuned.py.
+LIB_PATH = os.path.join(_HERE, "libmyfa_gfx950.so")
 TUNING_LIB_PATH = os.path.join(_HERE, "libmyfa_gfx950_tuning.so")
 
 ABI_VERSION = 3

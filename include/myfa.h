@@ -254,6 +254,11 @@ int myfa_attn_bwd_bhnd_static_ws(const void* q, const void* k, const void* v, co
  * own tiled kernel behind my_matmul / my_matmul_out (launch_matmul_kernel,
  * csrc/my_flash_attn/matmul.cu:22-62, called from csrc/api.cpp:13-66).  Every
  * element of c is written (the reference zero-fills first, api.cpp:46).
+ * c must be device memory and may not overlap a or b: small outputs with a long k are computed
+ * by two workgroups per block that add their halves into a c the launcher has zeroed first, so
+ * an input that shares storage with c would be cleared before it is read (the reference's own
+ * kernel reads A and B while it writes `out`, so aliasing is not defined there either,
+ * csrc/api.cpp:13-38).  Overlapping ranges are refused with MYFA_E_INVALID.
  */
 int myfa_matmul_f32(const float* a, const float* b, float* c, int64_t m, int64_t k, int64_t n, void* stream);
 

@@ -57,6 +57,11 @@ VARIANTS = [
     # weight is 2^x against a stale max instead of the exact 1, and the rounding of that weight to the
     # tensor type (relative 2^-8 in bfloat16, times |v| up to ~5) adds to the output's own rounding
     (dict(attn_variant=2, attn_spec=1), 1.0, 4e-2), (dict(attn_variant=2, attn_spec=1, attn_thr=60), 1.0, 4e-2),
+    # the resident-workgroup build (a workgroup streams through a list of query blocks): the library's
+    # choices, both softmax forms forced, and two workgroups for the 16 query blocks of this problem
+    (dict(attn_variant=3), 1.0, LP_ATOL), (dict(attn_variant=3), None, LP_ATOL),
+    (dict(attn_variant=3, attn_spec=0, attn_thr=0), 1.0, LP_ATOL), (dict(attn_variant=3, attn_spec=1, attn_thr=0), 1.0, LP_ATOL),
+    (dict(attn_variant=3, attn_spec=1, attn_thr=5, attn_wgs=2), None, LP_ATOL), (dict(attn_variant=3, attn_spec=0, attn_wgs=3), 1.0, LP_ATOL),
 ]
 
 
@@ -78,7 +83,7 @@ def test_schedules_shapes_and_deferred_max_agree(tuned, knobs, scale, atol, dtyp
     assert _maxdiff(lse.cpu().numpy(), ref_cpu.attention_lse(qr, kr, scale=scale)) <= 2e-3
 
 
-@pytest.mark.parametrize("variant,spec", [(1, -1), (2, 0), (2, 1)])
+@pytest.mark.parametrize("variant,spec", [(1, -1), (2, 0), (2, 1), (3, 0), (3, 1)])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("shape", [
@@ -100,7 +105,32 @@ def test_mfma_shapes_vs_oracle(tuned, variant, spec, causal, dtype, shape):
     assert _maxdiff(lse.cpu().numpy(), ref_cpu.attention_lse(qr, kr, scale=scale, causal=causal)) <= 1e-3
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("wgs", [1, 3, 8, 11, 0])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("shape,dtype", [
+    ((2, 3, 64, 64), torch.float16), ((1, 5, 40, 128), torch.bfloat16), ((2, 2, 700, 128), torch.bfloat16),
+    ((1, 3, 1300, 64), torch.float16), ((3, 2, 257, 128), torch.float16), ((1, 4, 130, 64), torch.bfloat16),
+    ((2, 2, 1, 128), torch.bfloat16), ((1, 2, 520, 72), torch.bfloat16),
+])
+def test_resident_workgroups_stream_through_their_items(tuned, wgs, causal, shape, dtype):
+    """The resident-workgroup build with FEWER workgroups than query blocks: every workgroup works
+    through several (head, query block) items back to back -- rings, Q fragments and the running
+    softmax state turn over between items, also for items of a single tile (N <= 64) and under the
+    causal mask, where items differ in length."""
+    B, H, N, d = shape
+    scale = d ** -0.5
+    tuned.set(attn_variant=3, attn_wgs=wgs)
+    torch.manual_seed(3)
+    q, k, v = (torch.randn(B, H, N, d, dtype=torch.float32) for _ in range(3))
+    out, lse = tuned.flash_attn_fwd(q.cuda().to(dtype), k.cuda().to(dtype), v.cuda().to(dtype),
+                                    scale=scale, causal=causal, return_lse=True)
+    qr, kr, vr = (_rounded(x, dtype) for x in (q, k, v))
+    assert bool(torch.isfinite(out.float()).all())
+    assert _maxdiff(out.float().cpu().numpy(), ref_cpu.attention_bhnd(qr, kr, vr, scale=scale, causal=causal)) <= LP_ATOL
+    assert _maxdiff(lse.cpu().numpy(), ref_cpu.attention_lse(qr, kr, scale=scale, causal=causal)) <= 1e-3
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_memory_behind_the_tensors_never_reaches_the_output(tuned, variant):
     """Fetches past the end of K/V must come back as zeros (buffer bounds), never as the NaNs
     planted behind the tensors."""
