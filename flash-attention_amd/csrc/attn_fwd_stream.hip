@@ -238,18 +238,18 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
         vaddr[1] = vbase[1] + (4 + vslot) * TILE_B;
         asm volatile("" : "+v"(kaddr), "+v"(vaddr[0]), "+v"(vaddr[1]));
     };
+    // ring addresses of the coming matrix phase: formed in the vector phase in front of it (for its
+    // `prefill`) and kept, so that the matrix phase opens with its first MFMA
+    int ck_addr = 0, cv_addr[2] = {0, 0};
     auto prefill = [&](int kslot, int vslot, auto first_, auto last_) __attribute__((always_inline)) {
         constexpr int FIRST = decltype(first_)::value, LAST = decltype(last_)::value;
-        int kaddr, vaddr[2];
-        slot_addr(kslot, vslot, kaddr, vaddr);
+        slot_addr(kslot, vslot, ck_addr, cv_addr);
 #pragma unroll
         for (int i = FIRST; i < FIRST + FW; ++i)
-            if (i < LAST) win[(i - FIRST) % FW] = frag(kaddr, vaddr, i);
+            if (i < LAST) win[(i - FIRST) % FW] = frag(ck_addr, cv_addr, i);
     };
-    auto mma_stream = [&](int kslot, int vslot, auto first_, auto last_, auto&& after) __attribute__((always_inline)) {
+    auto mma_stream = [&](auto first_, auto last_, auto&& after) __attribute__((always_inline)) {
         constexpr int FIRST = decltype(first_)::value, LAST = decltype(last_)::value;
-        int kaddr, vaddr[2];
-        slot_addr(kslot, vslot, kaddr, vaddr);
         if constexpr (FIRST < NQ) {
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
@@ -269,7 +269,7 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
                 o[db][0] = M::run(a, pb[st][0], o[db][0]);
                 o[db][1] = M::run(a, pb[st][1], o[db][1]);
             }
-            if (i + FW < LAST) win[(i - FIRST) % FW] = frag(kaddr, vaddr, i + FW);
+            if (i + FW < LAST) win[(i - FIRST) % FW] = frag(ck_addr, cv_addr, i + FW);
             after(i);
             // pin the order: left alone, the scheduler sinks every read to just before its MFMA
             __builtin_amdgcn_sched_barrier(0);
@@ -452,6 +452,19 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
         __builtin_amdgcn_s_waitcnt(0x0F70);
         asm volatile("" ::: "memory");
     };
+    // Behind dma_wait() no Q load is in flight either.  The compiler does not conclude that across the
+    // loops (it opened every matrix phase with five waits on the Q registers): passing the fragments
+    // through an empty asm statement makes them values defined here, with no load attached.
+    auto q_settled = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                u32x4 w = __builtin_bit_cast(u32x4, qf[qb][ks]);
+                asm volatile("" : "+v"(w));
+                qf[qb][ks] = __builtin_bit_cast(vec8, w);
+            }
+    };
     auto phase_barrier = [&]() __attribute__((always_inline)) {
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -482,7 +495,7 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
 
     prefill(0, 0, IC<0>{}, IC<NQ>{});
     // S(0) = K(0) Q^T, with the fetches of the stream's tiles K(2), V(1) behind its last fragment request
-    mma_stream(0, 0, IC<0>{}, IC<NQ>{}, [&](int i) __attribute__((always_inline)) {
+    mma_stream(IC<0>{}, IC<NQ>{}, [&](int i) __attribute__((always_inline)) {
         constexpr int L0 = NQ - FW;
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
@@ -496,6 +509,7 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
     if (grp) __syncthreads();
     softmax(0, IC<1>{});
     dma_wait();                              // every wave's share of the five tiles is in before the barrier
+    q_settled();
     prefill(1, 0, IC<0>{}, IC<NQ + NP>{});   // first fragments of the next matrix phase: K of stream tile 1
     phase_barrier();
 
@@ -511,7 +525,7 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
         const int k3 = (k1 + 2) & 3;             // (u+3) % 4
         const int v1 = v0 == 2 ? 0 : v0 + 1;     // (u+1) % 3
         const int v2 = v1 == 2 ? 0 : v1 + 1;     // (u+2) % 3
-        mma_stream(k1, v0, IC<0>{}, IC<NQ + NP>{}, [&](int i) __attribute__((always_inline)) {
+        mma_stream(IC<0>{}, IC<NQ + NP>{}, [&](int i) __attribute__((always_inline)) {
             constexpr int L0 = NQ + NP - FW;     // no fragment requests from here on
 #pragma unroll
             for (int j = 0; j < LPT; ++j) {
@@ -530,6 +544,7 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
         const int k2 = (k1 + 1) & 3;
         const int v1 = v0 == 2 ? 0 : v0 + 1;
         dma_wait();
+        q_settled();
         prefill(k2, v1, IC<0>{}, IC<NQ + NP>{});
         phase_barrier();
         k1 = k2; v0 = v1;
