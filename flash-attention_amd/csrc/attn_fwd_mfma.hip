@@ -714,7 +714,7 @@ int attn_fwd_mfma16(const void* q, const void* k, const void* v, void* o, float*
                     int64_t heads, int64_t N, int64_t d, float scale, float thr, int spec, int xflags,
                     int dtype, bool causal, hipStream_t s);
 int attn_fwd_stream(const void* q, const void* k, const void* v, void* o, float* lse,
-                    int64_t heads, int64_t N, int64_t d, float scale, float thr, int spec, int wgs,
+                    int64_t heads, int64_t N, int64_t d, float scale, float thr, int spec, int pre, int wgs,
                     int dtype, bool causal, hipStream_t s);
 int attn_fwd_mfma_wide(const void* q, const void* k, const void* v, void* o, float* lse,
                        int64_t heads, int64_t N, int64_t d, float scale, float thr, int dtype, bool causal, hipStream_t s);
@@ -748,7 +748,7 @@ int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* l
     // ~6 % of its life).  Up to 64 it still loses (register spills at 128 registers per lane).
     if (variant == 3 || (variant < 0 && d > 64))
         return attn_fwd_stream(q, k, v, o, lse, heads, N, d, scale, tuning().attn_thr, tuning().attn_spec,
-                               tuning().attn_wgs, dtype, causal, s);
+                               tuning().attn_pre, tuning().attn_wgs, dtype, causal, s);
     if (variant == 2 || variant < 0)
         return attn_fwd_mfma16(q, k, v, o, lse, heads, N, d, scale, tuning().attn_thr, tuning().attn_spec,
                                tuning().attn_xflags, dtype, causal, s);

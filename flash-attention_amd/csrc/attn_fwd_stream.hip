@@ -49,7 +49,16 @@ constexpr int kPastEndS = 0x7FFF0000;
 // SPEC as in attn_fwd_mfma16_kernel: true = the weights of a tile are formed against the running
 // max as it stands and the tile's maxima are looked for only when a partial row sum passes `lim`;
 // false = the max of every tile, vote on its growth beyond `thr`.
-template <typename T, int D, bool CAUSAL, bool SPEC>
+// PRE (with SPEC, without the mask): the logits leave the matrix cores ready for the exponential.
+// Q is multiplied by scale * log2(e) when it arrives (one rounding to the element type per element,
+// once per item) and the accumulators of S = K Q^T start from minus the running max instead of
+// zero, so S' = scale log2(e) Q K^T - c comes out of the MFMA chain and the weights are exp2(S'):
+// the scale-and-subtract, a third of the vector phase's instructions, is gone from the common path.
+// `c` is the max the accumulators started from: the running max, except in an item's first tile,
+// whose S was formed beside the previous item's last tile and carries that item's max.
+// The launcher uses it only where logits are small (the regime it picks SPEC in): rounding
+// Q * scale * log2(e) to bfloat16 moves a logit by ~2^-9 of its size, 0.005 base-2 units at most there.
+template <typename T, int D, bool CAUSAL, bool SPEC, bool PRE = false>
 __global__ void __launch_bounds__(kThreadsS, D == 64 ? 4 : 2)
 attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* __restrict__ Vg,
                        T* __restrict__ Og, float* __restrict__ LSEg, int N, int nqblk, int hp, int nunits,
@@ -187,6 +196,23 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
     f32x4 s[4][2];
     vec8 qf[2][KS];
     vec8 pb[2][2];
+    static_assert(!PRE || (SPEC && !CAUSAL), "PRE goes with the speculative softmax of the unmasked build");
+    // PRE: what the accumulators of S start from, -c for the lane's two queries (every register of a
+    // tuple holds the same value: a lane's four accumulator rows are keys of one query)
+    f32x4 cneg[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cneg[qb][r] = 0.f;
+    [[maybe_unused]] int q_fresh = 0;            // PRE: Q fragments have arrived unscaled (wave-uniform)
+    auto scale_q = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[qb][ks][j] = (T)((float)qf[qb][ks][j] * sl2);
+    };
 
     // Q fragments of an item, straight into their registers: lane (i, g) holds, for query block qb
     // and k-step ks, Q[q0 + 32 wave + 16 qb + i][32 ks + 8 g .. + 7].  Rows past N and columns past
@@ -254,9 +280,13 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb)
+                for (int qb = 0; qb < 2; ++qb) {
+                    if constexpr (PRE) s[kb][qb] = cneg[qb];
+                    else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) s[kb][qb][r] = 0.f;
+                        for (int r = 0; r < 4; ++r) s[kb][qb][r] = 0.f;
+                    }
+                }
         }
 #pragma unroll
         for (int i = FIRST; i < LAST; ++i) {
@@ -287,8 +317,9 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
     // and against a running max of -inf every weight and with it every row sum is infinite (or NaN
     // where the logit is masked), which sends the speculative path back and trips the other
     // path's vote; O and l, still zero, are scaled by exp2(-inf) = 0.
-    auto softmax = [&](int kv0, auto mask_flag) __attribute__((always_inline)) {
+    auto softmax = [&](int kv0, auto mask_flag, auto first_flag) __attribute__((always_inline)) {
         constexpr bool MASK = decltype(mask_flag)::value != 0;
+        [[maybe_unused]] constexpr bool FIRST = decltype(first_flag)::value != 0;   // an item's first tile
         // keys past N, and under the causal mask keys after the lane's query rows; a tile the
         // wave's first row already covers entirely needs no look
         if (MASK && (kv0 + kBKVS > N || (CAUSAL && kv0 + kBKVS - 1 > cur.q0 + 32 * wave_u))) {
@@ -351,7 +382,45 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
                     }
             }
         };
-        if constexpr (SPECULATE) {
+        if constexpr (PRE) {
+            // the logits arrive as s' = scale log2(e) q.k - c
+            auto weights_pre = [&](const float (&delta)[2], auto shifted) __attribute__((always_inline)) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if constexpr (decltype(shifted)::value) p[kb][qb][r] = __builtin_amdgcn_exp2f(s[kb][qb][r] - delta[qb]);
+                            else p[kb][qb][r] = __builtin_amdgcn_exp2f(s[kb][qb][r]);
+                            if (kb == 0 && r == 0) psum[qb] = p[kb][qb][r];
+                            else psum[qb] += p[kb][qb][r];
+                        }
+                }
+            };
+            const float none[2] = {0.f, 0.f};
+            bool back = true;                    // an item's first tile always looks for its maxima (m is -inf)
+            if constexpr (!FIRST) {
+                weights_pre(none, IC<0>{});
+                // negated comparisons: a NaN or an infinite sum goes back too
+                back = __builtin_amdgcn_ballot_w64(!(psum[0] <= lim) || !(psum[1] <= lim)) != 0;   // wave-uniform
+            }
+            if (back) {
+                float tmax[2];
+                lane_max(tmax);
+                const Pair mt_ = four_row_reduce(tmax[0], tmax[1], RawMaxOp{});
+                const float mt[2] = {mt_.a - cneg[0][0], mt_.b - cneg[1][0]};   // the tile's maxima, shift undone
+                float delta[2];
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) delta[qb] = fmaxf(m[qb], mt[qb]) + cneg[qb][0];   // new max - c
+                move_max(mt);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cneg[qb][r] = -m[qb];
+                weights_pre(delta, IC<1>{});
+            }
+        } else if constexpr (SPECULATE) {
             weights();
             // negated comparisons: a NaN or an infinite sum goes back too
             if (__builtin_amdgcn_ballot_w64(!(psum[0] <= lim) || !(psum[1] <= lim)) != 0) {   // wave-uniform
@@ -473,7 +542,20 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
     // Behind the matrix phase that formed the LAST S of item x (tile T-1): the Q fragments are free,
     // the next item's go into them (they have the following vector phase to arrive).
     auto q_turnover = [&](Seq nq) __attribute__((always_inline)) {
-        if (nq.ps < my_units) load_q(decode(nq));
+        if (nq.ps < my_units) {
+            load_q(decode(nq));
+            q_fresh = 1;
+        }
+    };
+    // behind dma_wait(): fragments that arrived in this phase get their scale (PRE)
+    auto q_arrived = [&]() __attribute__((always_inline)) {
+        if constexpr (PRE) {
+            if (q_fresh) {
+                scale_q();
+                q_fresh = 0;
+            }
+        }
+        q_settled();
     };
 
     // ---- prologue: the first item's Q fragments into their registers, this workgroup's first three
@@ -485,6 +567,7 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
     for (int i = 0; i < LPT; ++i) fetch_piece(kc, 0, i);
     advance(kc, Kg);
     dma_wait();
+    if constexpr (PRE) scale_q();
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < LPT; ++i) fetch_piece(vc, 4 * TILE_B, i);
@@ -507,9 +590,9 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
     advance(vc, Vg);
     if (cur.nt == 1) q_turnover(seq_next(cq, cur.pair2));
     if (grp) __syncthreads();
-    softmax(0, IC<1>{});
+    softmax(0, IC<1>{}, IC<1>{});
     dma_wait();                              // every wave's share of the five tiles is in before the barrier
-    q_settled();
+    q_arrived();
     prefill(1, 0, IC<0>{}, IC<NQ + NP>{});   // first fragments of the next matrix phase: K of stream tile 1
     phase_barrier();
 
@@ -544,7 +627,7 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
         const int k2 = (k1 + 1) & 3;
         const int v1 = v0 == 2 ? 0 : v0 + 1;
         dma_wait();
-        q_settled();
+        q_arrived();
         prefill(k2, v1, IC<0>{}, IC<NQ + NP>{});
         phase_barrier();
         k1 = k2; v0 = v1;
@@ -554,7 +637,7 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
         phase_barrier();                         // the fetches just issued stay in flight across it
         turn();
         if (t + 2 == cur.nt) q_turnover(seq_next(cq, cur.pair2));   // S(T-1) is formed: the Q registers turn over
-        softmax((t + 1) * kBKVS, mask_flag);     // X(t+1)
+        softmax((t + 1) * kBKVS, mask_flag, IC<0>{});   // X(t+1)
         phase_tail();
     };
 
@@ -584,7 +667,7 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
         cur = nxt;
         cq = nq;
         qrow0 = cur.q0 + wave_u * 32 + i16;
-        softmax(0, IC<1>{});                     // X(0) of the new item
+        softmax(0, IC<1>{}, IC<1>{});            // X(0) of the new item
         phase_tail();
     }
     if (grp == 0) __syncthreads();   // the leading half meets the lagging half's last barrier
@@ -614,7 +697,7 @@ int cu_count_current() {
 
 template <typename T, int D>
 int launch_stream(const void* q, const void* k, const void* v, void* o, float* lse,
-                  int64_t heads, int64_t N, int64_t d, float scale, float thr, bool spec, bool causal, int wgs, hipStream_t s) {
+                  int64_t heads, int64_t N, int64_t d, float scale, float thr, bool spec, bool pre, bool causal, int wgs, hipStream_t s) {
     if (N * d * 2 >= (int64_t)kPastEndS) return fail(MYFA_E_UNSUPPORTED, "attention: N*d=%lld per head too large", (long long)(N * d));
     const int64_t nqblk = cdiv(N, kBQS);
     // units of work: query blocks, or under the causal mask pairs of mirrored query blocks of a head
@@ -638,6 +721,7 @@ int launch_stream(const void* q, const void* k, const void* v, void* o, float* l
                       static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)hp, (int)nunits, sl2, thr, lim, (int)d);
     };
     if (causal) go(attn_fwd_stream_kernel<T, D, true, false>);
+    else if (spec && pre) go(attn_fwd_stream_kernel<T, D, false, true, true>);
     else if (spec) go(attn_fwd_stream_kernel<T, D, false, true>);
     else go(attn_fwd_stream_kernel<T, D, false, false>);
     return check_launch("attn_fwd_stream");
@@ -649,20 +733,28 @@ int launch_stream(const void* q, const void* k, const void* v, void* o, float* l
 // spec, thr: as attn_fwd_mfma16 (attn_fwd_mfma16.hip): < 0 = the library's choice.
 // wgs: workgroups in the grid; <= 0 = as many as the chip holds at once.
 int attn_fwd_stream(const void* q, const void* k, const void* v, void* o, float* lse,
-                    int64_t heads, int64_t N, int64_t d, float scale, float thr, int spec, int wgs,
+                    int64_t heads, int64_t N, int64_t d, float scale, float thr, int spec, int pre, int wgs,
                     int dtype, bool causal, hipStream_t s) {
     if (heads <= 0 || N <= 0) return MYFA_OK;
     const bool sp = spec < 0 ? scale * 1.4426950408889634f * sqrtf((float)d) <= 4.0f : spec != 0;
     if (thr < 0.f) thr = !sp || causal ? 8.f : dtype == MYFA_BF16 ? 30.f : 12.f;
     if (dtype == MYFA_F16 && thr > 15.f) thr = 15.f;
     if (thr > 60.f) thr = 60.f;
+    // pre: < 0 = the library's choice: wherever the speculative build runs and no row statistic is
+    // asked for (inference).  The rounding of Q * scale * log2(e) moves a logit by ~2^-9 of its size --
+    // the order of the rounding the 16-bit inputs already carry, and far inside the output's bound --
+    // but the row log-sum-exp moves with its largest logits (0.01 for a logit of 35), and a backward
+    // that recomputes the logits from the unscaled Q wants the statistic of exactly those logits.
+    // Else forced on / off (tuning flavour).
+    // (Head dims up to 64: never by itself -- that build already spills registers and loses a third with it.)
+    const bool pr = sp && !causal && (pre < 0 ? lse == nullptr && d > 64 : pre != 0);
     // head dims that are multiples of 8 run on the next build up, the missing columns read as zeros
     if (d >= 8 && d <= 128 && d % 8 == 0) {
         const bool big = d > 64;
-        if (dtype == MYFA_BF16) return big ? launch_stream<__bf16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, sp, causal, wgs, s)
-                                           : launch_stream<__bf16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, sp, causal, wgs, s);
-        if (dtype == MYFA_F16)  return big ? launch_stream<_Float16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, sp, causal, wgs, s)
-                                           : launch_stream<_Float16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, sp, causal, wgs, s);
+        if (dtype == MYFA_BF16) return big ? launch_stream<__bf16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, causal, wgs, s)
+                                           : launch_stream<__bf16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, causal, wgs, s);
+        if (dtype == MYFA_F16)  return big ? launch_stream<_Float16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, causal, wgs, s)
+                                           : launch_stream<_Float16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, causal, wgs, s);
     }
     return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16): head dim %lld is not a multiple of 8 in 8..128", (long long)d);
 }

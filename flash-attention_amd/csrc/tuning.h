@@ -28,6 +28,9 @@ struct Tuning {
     // timing probes of the stamped 16x16x32 build (wrong results): 8 = no tile fetches in the loop,
     // 16 = no vector phase
     int attn_xflags = 0;
+    // resident-workgroup build, speculative softmax: 1 = Q pre-multiplied by scale * log2(e) and the
+    // running max folded into the accumulators' start value, 0 = not, -1 = the library's choice
+    int attn_pre = -1;
     // resident-workgroup build: workgroups in the grid (0 = as many as the chip holds at once)
     int attn_wgs = 0;
     // device buffer for the stamped (cycle-counting) diagnostic build, 24 u64 per workgroup

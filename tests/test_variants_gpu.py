@@ -60,8 +60,13 @@ VARIANTS = [
     # the resident-workgroup build (a workgroup streams through a list of query blocks): the library's
     # choices, both softmax forms forced, and two workgroups for the 16 query blocks of this problem
     (dict(attn_variant=3), 1.0, LP_ATOL), (dict(attn_variant=3), None, LP_ATOL),
-    (dict(attn_variant=3, attn_spec=0, attn_thr=0), 1.0, LP_ATOL), (dict(attn_variant=3, attn_spec=1, attn_thr=0), 1.0, LP_ATOL),
+    (dict(attn_variant=3, attn_spec=0, attn_thr=0), 1.0, LP_ATOL), (dict(attn_variant=3, attn_spec=1, attn_pre=0, attn_thr=0), 1.0, LP_ATOL),
     (dict(attn_variant=3, attn_spec=1, attn_thr=5, attn_wgs=2), None, LP_ATOL), (dict(attn_variant=3, attn_spec=0, attn_wgs=3), 1.0, LP_ATOL),
+    # ... with and without Q pre-multiplied by scale * log2(e) and the running max folded into the
+    # accumulators' start value (the library's choice wherever it picks the speculative softmax)
+    (dict(attn_variant=3, attn_spec=1, attn_pre=0), None, LP_ATOL), (dict(attn_variant=3, attn_spec=1, attn_pre=1), None, LP_ATOL),
+    (dict(attn_variant=3, attn_spec=1, attn_pre=1, attn_thr=0, attn_wgs=3), None, LP_ATOL),
+    (dict(attn_variant=3, attn_spec=1, attn_pre=1, attn_thr=60, attn_wgs=5), None, LP_ATOL),
 ]
 
 
@@ -77,13 +82,20 @@ def test_schedules_shapes_and_deferred_max_agree(tuned, knobs, scale, atol, dtyp
     q, k, v = (torch.randn(2, 2, N, d) for _ in range(3))
     for row, key in [(0, 130), (5, 999), (15, 3), (16, 700), (31, 64), (32, 65), (100, 300), (255, 575), (256, 1), (999, 998)]:
         k[:, :, key] = q[:, :, row] * 3.0
-    out, lse = tuned.flash_attn_fwd(q.cuda().to(dtype), k.cuda().to(dtype), v.cuda().to(dtype), scale=scale, return_lse=True)
+    qd, kd, vd = (x.cuda().to(dtype) for x in (q, k, v))
+    out, lse = tuned.flash_attn_fwd(qd, kd, vd, scale=scale, return_lse=True)
     qr, kr, vr = (_rounded(x, dtype) for x in (q, k, v))
-    assert _maxdiff(out.float().cpu().numpy(), ref_cpu.attention_bhnd(qr, kr, vr, scale=scale)) <= atol
-    assert _maxdiff(lse.cpu().numpy(), ref_cpu.attention_lse(qr, kr, scale=scale)) <= 2e-3
+    ref = ref_cpu.attention_bhnd(qr, kr, vr, scale=scale)
+    assert _maxdiff(out.float().cpu().numpy(), ref) <= atol
+    # with Q pre-multiplied by scale * log2(e) (forced here: the library does not do it when the row
+    # statistic is asked for) a logit of 50 moves by up to ~2^-8 of its size, and the statistic with it
+    lse_tol = 6e-2 if knobs.get("attn_pre") == 1 else 2e-3
+    assert _maxdiff(lse.cpu().numpy(), ref_cpu.attention_lse(qr, kr, scale=scale)) <= lse_tol
+    # the call without the row statistic (where the library may take a faster route) meets the same bound
+    assert _maxdiff(tuned.flash_attn_fwd(qd, kd, vd, scale=scale).float().cpu().numpy(), ref) <= atol
 
 
-@pytest.mark.parametrize("variant,spec", [(1, -1), (2, 0), (2, 1), (3, 0), (3, 1)])
+@pytest.mark.parametrize("variant,spec", [(1, -1), (2, 0), (2, 1), (3, 0), (3, 1), (3, -1)])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("shape", [
@@ -122,12 +134,17 @@ def test_resident_workgroups_stream_through_their_items(tuned, wgs, causal, shap
     tuned.set(attn_variant=3, attn_wgs=wgs)
     torch.manual_seed(3)
     q, k, v = (torch.randn(B, H, N, d, dtype=torch.float32) for _ in range(3))
-    out, lse = tuned.flash_attn_fwd(q.cuda().to(dtype), k.cuda().to(dtype), v.cuda().to(dtype),
-                                    scale=scale, causal=causal, return_lse=True)
+    qd, kd, vd = (x.cuda().to(dtype) for x in (q, k, v))
+    out, lse = tuned.flash_attn_fwd(qd, kd, vd, scale=scale, causal=causal, return_lse=True)
     qr, kr, vr = (_rounded(x, dtype) for x in (q, k, v))
+    ref = ref_cpu.attention_bhnd(qr, kr, vr, scale=scale, causal=causal)
     assert bool(torch.isfinite(out.float()).all())
-    assert _maxdiff(out.float().cpu().numpy(), ref_cpu.attention_bhnd(qr, kr, vr, scale=scale, causal=causal)) <= LP_ATOL
+    assert _maxdiff(out.float().cpu().numpy(), ref) <= LP_ATOL
     assert _maxdiff(lse.cpu().numpy(), ref_cpu.attention_lse(qr, kr, scale=scale, causal=causal)) <= 1e-3
+    # without the row statistic the library pre-multiplies Q by scale * log2(e) (unmasked launches)
+    out2 = tuned.flash_attn_fwd(qd, kd, vd, scale=scale, causal=causal)
+    assert bool(torch.isfinite(out2.float()).all())
+    assert _maxdiff(out2.float().cpu().numpy(), ref) <= LP_ATOL
 
 
 @pytest.mark.parametrize("variant", [1, 2, 3])
