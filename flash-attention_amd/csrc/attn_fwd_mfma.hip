@@ -11,7 +11,7 @@
 // registers until one final division by l.
 //
 // Two kernels in this file, both on v_mfma_f32_32x32x16 (the 16x16x32 build of the same design is
-// attn_fwd_mfma16.hip; the launcher at the bottom picks between them):
+// attn_fwd_mfma16.hip; attn_fwd_dispatch.hip picks between them):
 //   attn_fwd_mfma_pp_kernel  the first ping-pong build (only the tuning flavour can select it): K/V tiles fetched by LDS-DMA
 //                            (buffer_load ... lds) into rings of 4 / 3 slots, the two waves of a
 //                            SIMD in opposite phases (matrix / softmax), one s_barrier per phase.
@@ -37,6 +37,9 @@
 //   read from the row-major V tile with the transposing LDS read
 //   ds_read_b64_tr_b16 in that same key order.  O^T again has the query on the
 //   lane, so the per-row rescale and the final 1/l are per-lane scalars.
+// Compiled into the tuning flavour of the library only (-DMYFA_TUNING): the shipped library's
+// dispatch (attn_fwd_dispatch.hip) never selects these kernels.
+#ifdef MYFA_TUNING
 #include "attn_mfma_common.h"
 #include "tuning.h"
 
@@ -710,49 +713,10 @@ int launch(const void* q, const void* k, const void* v, void* o, float* lse,
 
 }  // namespace
 
-int attn_fwd_mfma16(const void* q, const void* k, const void* v, void* o, float* lse,
-                    int64_t heads, int64_t N, int64_t d, float scale, float thr, int spec, int xflags,
-                    int dtype, bool causal, hipStream_t s);
-int attn_fwd_stream(const void* q, const void* k, const void* v, void* o, float* lse,
-                    int64_t heads, int64_t N, int64_t d, float scale, float thr, int spec, int pre, int wgs,
-                    int dtype, bool causal, hipStream_t s);
-int attn_fwd_mfma_wide(const void* q, const void* k, const void* v, void* o, float* lse,
-                       int64_t heads, int64_t N, int64_t d, float scale, float thr, int dtype, bool causal, hipStream_t s);
-
-// The kernel the dispatch below picks (kept beside it so that the two cannot drift apart).
-const char* attn_fwd_mfma_kernel_name(int64_t d, [[maybe_unused]] int dtype, [[maybe_unused]] bool causal) {
-    if (d < 8 || d > 256 || d % 8 != 0) return nullptr;
-    if (d > 128) return "attn_fwd_mfma_wide_kernel";
-    const int variant = tuning().attn_variant;
-    if (variant == 3 || (variant < 0 && d > 64)) return "attn_fwd_stream_kernel";
-    if (variant == 2 || variant < 0) return "attn_fwd_mfma16_kernel";
-    return variant == 0 && !causal && (d == 64 || d == 128) ? "attn_fwd_mfma_kernel" : "attn_fwd_mfma_pp_kernel";
-}
-
-// dtype: MYFA_F16 or MYFA_BF16; d: a multiple of 8 in 8..256; heads = B*H
-int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* lse,
-                  int64_t heads, int64_t N, int64_t d, float scale, int dtype, bool causal, hipStream_t s) {
-    if (!(scale > 0.f)) return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16): scale must be > 0, got %g", (double)scale);
-    if (N > 0x7fffffffLL / 256) return fail(MYFA_E_UNSUPPORTED, "attention: N=%lld too large", (long long)N);
-    // The 16x16x32 build is the default: the chip holds a higher clock on that MFMA shape (random
-    // operands; measured +6..12 % at d = 128, +2 % at d = 64 without a mask).  Under the causal mask
-    // its tile loop is split in two, unmasked tiles in front of the workgroup's rows and the masked
-    // tiles on the diagonal, so the first loop is the unmasked kernel's code: even with the 32x32x16
-    // build at d = 128 (N = 4096; +1 % at N = 16384) and +32..38 % at d = 64.
-    const float thr_classic = tuning().attn_thr < 0.f ? 8.f : tuning().attn_thr;
-    if (d > 128) return attn_fwd_mfma_wide(q, k, v, o, lse, heads, N, d, scale, thr_classic, dtype, causal, s);
-    const int variant = tuning().attn_variant;
-    // Head dims above 64: the resident-workgroup build (one workgroup per CU working through a list
-    // of query blocks as one unbroken stream of tiles: +4..5 % on random operands, +9.5 % in cycles
-    // over one workgroup per query block, whose fill and drain leave the CU's matrix cores idle for
-    // ~6 % of its life).  Up to 64 it still loses (register spills at 128 registers per lane).
-    if (variant == 3 || (variant < 0 && d > 64))
-        return attn_fwd_stream(q, k, v, o, lse, heads, N, d, scale, tuning().attn_thr, tuning().attn_spec,
-                               tuning().attn_pre, tuning().attn_wgs, dtype, causal, s);
-    if (variant == 2 || variant < 0)
-        return attn_fwd_mfma16(q, k, v, o, lse, heads, N, d, scale, tuning().attn_thr, tuning().attn_spec,
-                               tuning().attn_xflags, dtype, causal, s);
-    // head dims that are multiples of 8 run on the next build up, the missing columns read as zeros
+// The 32x32x16 builds (tuning flavour: attn_variant 0 and 1).  dtype: MYFA_F16 or MYFA_BF16;
+// d: a multiple of 8 in 8..128 (run on the next build up, the missing columns read as zeros).
+int attn_fwd_mfma32(const void* q, const void* k, const void* v, void* o, float* lse,
+                    int64_t heads, int64_t N, int64_t d, float scale, int dtype, bool causal, hipStream_t s) {
     if (d >= 8 && d <= 128 && d % 8 == 0) {
         const bool big = d > 64;
         if (dtype == MYFA_BF16) return big ? launch<__bf16, 128>(q, k, v, o, lse, heads, N, d, scale, causal, s)
@@ -760,7 +724,8 @@ int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* l
         if (dtype == MYFA_F16)  return big ? launch<_Float16, 128>(q, k, v, o, lse, heads, N, d, scale, causal, s)
                                            : launch<_Float16, 64>(q, k, v, o, lse, heads, N, d, scale, causal, s);
     }
-    return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16): head dim %lld is not a multiple of 8 in 8..256", (long long)d);
+    return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16): head dim %lld is not a multiple of 8 in 8..128", (long long)d);
 }
 
 }  // namespace myfa
+#endif  // MYFA_TUNING

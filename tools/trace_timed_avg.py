@@ -9,7 +9,7 @@ import csv
 import sys
 
 path, k = sys.argv[1], int(sys.argv[2])
-name = sys.argv[3] if len(sys.argv) > 3 else "attn_fwd_mfma16_kernel"
+name = sys.argv[3] if len(sys.argv) > 3 else "attn_fwd_"
 rows = [r for r in csv.DictReader(open(path)) if name in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
