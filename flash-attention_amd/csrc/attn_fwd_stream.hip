@@ -46,6 +46,16 @@ constexpr int kBKVS = 64;              // keys per tile
 // added to it cannot wrap: fetches from there read zero without touching memory.
 constexpr int kPastEndS = 0x7FFF0000;
 
+// x = KEY > t ? ninf : x, KEY an inline constant (0..64): one compare into VCC, one select.
+template <int KEY>
+__device__ __forceinline__ float hide_past(float x, [[maybe_unused]] int t, [[maybe_unused]] float ninf) {
+    static_assert(KEY >= 0 && KEY <= 64, "inline constant");
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_cmp_gt_i32 vcc, %2, %1\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(x) : "v"(t), "n"(KEY), "v"(ninf) : "vcc");
+#endif
+    return x;
+}
+
 // SPEC as in attn_fwd_mfma16_kernel: true = the weights of a tile are formed against the running
 // max as it stands and the tile's maxima are looked for only when a partial row sum passes `lim`;
 // false = the max of every tile, vote on its growth beyond `thr`.
@@ -196,7 +206,7 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
     f32x4 s[4][2];
     vec8 qf[2][KS];
     vec8 pb[2][2];
-    static_assert(!PRE || (SPEC && !CAUSAL), "PRE goes with the speculative softmax of the unmasked build");
+    static_assert(!PRE || SPEC, "PRE goes with the speculative softmax");
     // PRE: what the accumulators of S start from, -c for the lane's two queries (every register of a
     // tuple holds the same value: a lane's four accumulator rows are keys of one query)
     f32x4 cneg[2];
@@ -323,15 +333,24 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
         // keys past N, and under the causal mask keys after the lane's query rows; a tile the
         // wave's first row already covers entirely needs no look
         if (MASK && (kv0 + kBKVS > N || (CAUSAL && kv0 + kBKVS - 1 > cur.q0 + 32 * wave_u))) {
+            // Key kv0 + 16 kb + 4 g + r is hidden from the lane's query of block qb when it lies past
+            // lim = min(query row, N - 1): with t = lim - kv0 - 4 g per lane, when 16 kb + r > t.  Written
+            // out as compare / select pairs on VCC with the tile-relative key as an inline constant: two
+            // instructions per logit and no scalar registers (left to the compiler the 32 comparisons
+            // come first, each mask in a scalar pair of its own, and the causal builds spill scalars).
+            [[maybe_unused]] int t_[2];
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+            for (int qb = 0; qb < 2; ++qb) t_[qb] = (CAUSAL ? min(qrow0 + 16 * qb, N - 1) : N - 1) - kv0 - 4 * g;
+            [[maybe_unused]] const float ninf = -INFINITY;
+            static_for<4>([&](auto kb_) {
+                static_for<4>([&](auto r_) {
+                    constexpr int kb = decltype(kb_)::value, r = decltype(r_)::value;
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kv0 + 16 * kb + 4 * g + r;
-                        if (key >= N || (CAUSAL && key > qrow0 + 16 * qb)) s[kb][qb][r] = -INFINITY;
+                    for (int qb = 0; qb < 2; ++qb) {
+                        s[kb][qb][r] = hide_past<16 * kb + r>(s[kb][qb][r], t_[qb], ninf);
                     }
+                });
+            });
         }
         // row max: four independent chains of v_max3_f32 (two per query), written out as single
         // instructions (vmax3 / vmax2: fmaxf would first quiet a possible signalling NaN in every
@@ -399,8 +418,10 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
                 }
             };
             const float none[2] = {0.f, 0.f};
-            bool back = true;                    // an item's first tile always looks for its maxima (m is -inf)
-            if constexpr (!FIRST) {
+            // an item's first tile always looks for its maxima (m is -inf), and so do the masked tiles on
+            // the diagonal of a causal launch (nothing is speculated on there: see SPECULATE)
+            bool back = true;
+            if constexpr (!FIRST && SPECULATE) {
                 weights_pre(none, IC<0>{});
                 // negated comparisons: a NaN or an infinite sum goes back too
                 back = __builtin_amdgcn_ballot_w64(!(psum[0] <= lim) || !(psum[1] <= lim)) != 0;   // wave-uniform
@@ -720,7 +741,8 @@ int launch_stream(const void* q, const void* k, const void* v, void* o, float* l
                       static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
                       static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)hp, (int)nunits, sl2, thr, lim, (int)d);
     };
-    if (causal) go(attn_fwd_stream_kernel<T, D, true, false>);
+    if (causal && spec && pre) go(attn_fwd_stream_kernel<T, D, true, true, true>);
+    else if (causal) go(attn_fwd_stream_kernel<T, D, true, false>);
     else if (spec && pre) go(attn_fwd_stream_kernel<T, D, false, true, true>);
     else if (spec) go(attn_fwd_stream_kernel<T, D, false, true>);
     else go(attn_fwd_stream_kernel<T, D, false, false>);
@@ -737,9 +759,6 @@ int attn_fwd_stream(const void* q, const void* k, const void* v, void* o, float*
                     int dtype, bool causal, hipStream_t s) {
     if (heads <= 0 || N <= 0) return MYFA_OK;
     const bool sp = spec < 0 ? scale * 1.4426950408889634f * sqrtf((float)d) <= 4.0f : spec != 0;
-    if (thr < 0.f) thr = !sp || causal ? 8.f : dtype == MYFA_BF16 ? 30.f : 12.f;
-    if (dtype == MYFA_F16 && thr > 15.f) thr = 15.f;
-    if (thr > 60.f) thr = 60.f;
     // pre: < 0 = the library's choice: wherever the speculative build runs and no row statistic is
     // asked for (inference).  The rounding of Q * scale * log2(e) moves a logit by ~2^-9 of its size --
     // the order of the rounding the 16-bit inputs already carry, and far inside the output's bound --
@@ -747,7 +766,10 @@ int attn_fwd_stream(const void* q, const void* k, const void* v, void* o, float*
     // that recomputes the logits from the unscaled Q wants the statistic of exactly those logits.
     // Else forced on / off (tuning flavour).
     // (Head dims up to 64: never by itself -- that build already spills registers and loses a third with it.)
-    const bool pr = sp && !causal && (pre < 0 ? lse == nullptr && d > 64 : pre != 0);
+    const bool pr = sp && (pre < 0 ? lse == nullptr && d > 64 : pre != 0);
+    if (thr < 0.f) thr = !sp || (causal && !pr) ? 8.f : dtype == MYFA_BF16 ? 30.f : 12.f;
+    if (dtype == MYFA_F16 && thr > 15.f) thr = 15.f;
+    if (thr > 60.f) thr = 60.f;
     // head dims that are multiples of 8 run on the next build up, the missing columns read as zeros
     if (d >= 8 && d <= 128 && d % 8 == 0) {
         const bool big = d > 64;
