@@ -16,7 +16,7 @@ int attn_fwd_mfma32(const void* q, const void* k, const void* v, void* o, float*
                     int64_t heads, int64_t N, int64_t d, float scale, int dtype, bool causal, hipStream_t s);
 #endif
 int attn_fwd_mfma16(const void* q, const void* k, const void* v, void* o, float* lse,
-                    int64_t heads, int64_t N, int64_t d, float scale, float thr, int spec, int xflags,
+                    int64_t heads, int64_t N, int64_t d, float scale, float thr, int spec, int pre, int xflags,
                     int dtype, bool causal, hipStream_t s);
 int attn_fwd_stream(const void* q, const void* k, const void* v, void* o, float* lse,
                     int64_t heads, int64_t N, int64_t d, float scale, float thr, int spec, int pre, int wgs,
@@ -56,7 +56,7 @@ int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* l
                                tuning().attn_pre, tuning().attn_wgs, dtype, causal, s);
     if (variant == 2 || variant < 0)
         return attn_fwd_mfma16(q, k, v, o, lse, heads, N, d, scale, tuning().attn_thr, tuning().attn_spec,
-                               tuning().attn_xflags, dtype, causal, s);
+                               tuning().attn_pre, tuning().attn_xflags, dtype, causal, s);
 #ifdef MYFA_TUNING
     return attn_fwd_mfma32(q, k, v, o, lse, heads, N, d, scale, dtype, causal, s);
 #else

@@ -64,7 +64,12 @@ __device__ __forceinline__ unsigned long long stamp16() {
     return t;
 }
 
-template <typename T, int D, bool CAUSAL = false, bool SPEC = true, bool STAMP = false>
+// PRE (with SPEC): as in attn_fwd_stream_kernel -- Q is multiplied by scale * log2(e) once, when its
+// fragments are read (one rounding to the element type per element), and the accumulators of
+// S = K Q^T start from minus the running max, so the weights are exp2 of what the matrix cores
+// deliver and the scale-and-subtract leaves the vector phase.  Launcher: only where the speculative
+// softmax runs and no row statistic is asked for.
+template <typename T, int D, bool CAUSAL = false, bool SPEC = true, bool STAMP = false, bool PRE = false>
 __global__ void __launch_bounds__(kThreads16, D == 64 ? 4 : 2)
 attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* __restrict__ Vg,
                        T* __restrict__ Og, float* __restrict__ LSEg, int N, int nqblk, int nwg,
@@ -170,6 +175,14 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
     f32x4 s[4][2];
     vec8 qf[2][KS];
     vec8 pb[2][2];
+    static_assert(!PRE || SPEC, "PRE goes with the speculative softmax");
+    // PRE: what the accumulators of S start from, -c for the lane's two queries (c = the running max
+    // they stand at; every register of a tuple holds the same value)
+    f32x4 cneg[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cneg[qb][r] = 0.f;
 
     constexpr int NQ = 4 * KS, NP = 2 * DB, FW = D == 64 ? 4 : 8;   // (4, 6 and 12 at D = 128: 3-6 % more cycles)
     // fragment i of the matrix phase: i < NQ: K fragment (kb = i / KS, ks = i % KS) of the K slot;
@@ -217,9 +230,13 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb)
+                for (int qb = 0; qb < 2; ++qb) {
+                    if constexpr (PRE) s[kb][qb] = cneg[qb];
+                    else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) s[kb][qb][r] = 0.f;
+                        for (int r = 0; r < 4; ++r) s[kb][qb][r] = 0.f;
+                    }
+                }
         }
 #pragma unroll
         for (int i = FIRST; i < LAST; ++i) {
@@ -247,20 +264,28 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
     // speculative path back and trips the other path's vote, and O and l are still zero when they
     // are scaled by exp2(-inf) = 0.  (A first tile with code of its own, no rescale in it, was
     // tried: the causal builds then spill 23-55 vector registers in their masked loop.)
-    auto softmax = [&](int kv0, auto mask_flag) __attribute__((always_inline)) {
+    auto softmax = [&](int kv0, auto mask_flag, auto first_flag) __attribute__((always_inline)) {
         constexpr bool MASK = decltype(mask_flag)::value != 0;
+        [[maybe_unused]] constexpr bool FIRST = decltype(first_flag)::value != 0;   // the workgroup's first tile
         // keys past N, and under the causal mask keys after the lane's query rows; a tile the
         // wave's first row already covers entirely needs no look
         if (MASK && (kv0 + kBKV16 > N || (CAUSAL && kv0 + kBKV16 - 1 > q0 + 32 * wave_u))) {
+            // Key kv0 + 16 kb + 4 g + r is hidden from the lane's query of block qb when it lies past
+            // lim = min(query row, N - 1): with t = lim - kv0 - 4 g per lane, when 16 kb + r > t.  Written
+            // out as compare / select pairs on VCC with the tile-relative key as an inline constant: two
+            // instructions per logit and no scalar registers (left to the compiler the 32 comparisons
+            // come first, each mask in a scalar pair of its own, and the causal builds spill scalars).
+            [[maybe_unused]] int t_[2];
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+            for (int qb = 0; qb < 2; ++qb) t_[qb] = (CAUSAL ? min(qrow0 + 16 * qb, N - 1) : N - 1) - kv0 - 4 * g;
+            [[maybe_unused]] const float ninf = -INFINITY;
+            static_for<4>([&](auto kb_) {
+                static_for<4>([&](auto r_) {
+                    constexpr int kb = decltype(kb_)::value, r = decltype(r_)::value;
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kv0 + 16 * kb + 4 * g + r;
-                        if (key >= N || (CAUSAL && key > qrow0 + 16 * qb)) s[kb][qb][r] = -INFINITY;
-                    }
+                    for (int qb = 0; qb < 2; ++qb) s[kb][qb][r] = hide_past<16 * kb + r>(s[kb][qb][r], t_[qb], ninf);
+                });
+            });
         }
         // row max: four independent chains of v_max3_f32 (two per query), written out as single
         // instructions (vmax3 / vmax2: fmaxf would first quiet a possible signalling NaN in every
@@ -315,7 +340,46 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
                     }
             }
         };
-        if constexpr (SPECULATE) {
+        if constexpr (PRE) {
+            // the logits arrive as s' = scale log2(e) q.k - c
+            auto weights_pre = [&](const float (&delta)[2], auto shifted) __attribute__((always_inline)) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if constexpr (decltype(shifted)::value) p[kb][qb][r] = __builtin_amdgcn_exp2f(s[kb][qb][r] - delta[qb]);
+                            else p[kb][qb][r] = __builtin_amdgcn_exp2f(s[kb][qb][r]);
+                            if (kb == 0 && r == 0) psum[qb] = p[kb][qb][r];
+                            else psum[qb] += p[kb][qb][r];
+                        }
+                }
+            };
+            const float none[2] = {0.f, 0.f};
+            // the first tile always looks for its maxima (m is -inf), and so do the masked tiles on the
+            // diagonal of a causal launch (nothing is speculated on there)
+            bool back = true;
+            if constexpr (!FIRST && SPECULATE) {
+                weights_pre(none, IC<0>{});
+                back = __builtin_amdgcn_ballot_w64(!(psum[0] <= lim) || !(psum[1] <= lim)) != 0;   // wave-uniform
+            }
+            if (back) {
+                float tmax[2];
+                lane_max(tmax);
+                const Pair mt_ = four_row_reduce(tmax[0], tmax[1], RawMaxOp{});
+                const float mt[2] = {mt_.a - cneg[0][0], mt_.b - cneg[1][0]};   // the tile's maxima, shift undone
+                float delta[2];
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) delta[qb] = fmaxf(m[qb], mt[qb]) + cneg[qb][0];   // new max - c
+                move_max(mt);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cneg[qb][r] = -m[qb];
+                weights_pre(delta, IC<1>{});
+            }
+        } else if constexpr (SPECULATE) {
             weights();
             // negated comparisons: a NaN or an infinite sum goes back too
             if (__builtin_amdgcn_ballot_w64(!(psum[0] <= lim) || !(psum[1] <= lim)) != 0) {   // wave-uniform
@@ -410,6 +474,14 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
         for (int ks = 0; ks < KS; ++ks)
             qf[qb][ks] = *reinterpret_cast<const vec8*>(lds + (kbase + qbyte) + (SUB_B * 2 * qb + 512 * ks));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (PRE) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[qb][ks][j] = (T)((float)qf[qb][ks][j] * sl2);
+    }
     __syncthreads();
 
     prefill(0, 0, IC<0>{}, IC<NQ>{});
@@ -423,7 +495,7 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
         }
     });
     if (grp) __syncthreads();
-    softmax(0, IC<1>{});
+    softmax(0, IC<1>{}, IC<1>{});
     dma_wait();                              // K(2), V(1): every wave's share is in before the barrier
     prefill(1, 0, IC<0>{}, IC<NQ + NP>{});   // first fragments of M(0): K(1), complete since the prologue
     phase_barrier();
@@ -454,9 +526,9 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
         if constexpr (STAMP) tc = stamp16();
         // ---- X(t+1)
         if constexpr (STAMP) {   // timing probe: no vector phase (wrong results)
-            if (!(probe & 16)) softmax((t + 1) * kBKV16, mask_flag);
+            if (!(probe & 16)) softmax((t + 1) * kBKV16, mask_flag, IC<0>{});
         } else {
-            softmax((t + 1) * kBKV16, mask_flag);
+            softmax((t + 1) * kBKV16, mask_flag, IC<0>{});
         }
         if constexpr (STAMP) tx = stamp16();
         dma_wait();                              // this wave's share of K(t+3), V(t+2) is in LDS
@@ -533,7 +605,7 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
 
 template <typename T, int D>
 int launch16(const void* q, const void* k, const void* v, void* o, float* lse,
-             int64_t heads, int64_t N, int64_t d, float scale, float thr, bool spec, int probe, bool causal, hipStream_t s) {
+             int64_t heads, int64_t N, int64_t d, float scale, float thr, bool spec, bool pre, int probe, bool causal, hipStream_t s) {
     if (N * d * 2 >= (int64_t)kPastEnd) return fail(MYFA_E_UNSUPPORTED, "attention: N*d=%lld per head too large", (long long)(N * d));
     const int64_t nqblk = cdiv(N, kBQ16);
     const int64_t nwg = heads * nqblk;
@@ -555,7 +627,9 @@ int launch16(const void* q, const void* k, const void* v, void* o, float* lse,
 #endif
     // Under the causal mask the speculative form loses (941 against 1004 TFLOP/s at the headline shape,
     // 726 against 777 at d = 64: the masked tiles take the other path anyway and the build carries both).
-    if (causal) go(attn_fwd_mfma16_kernel<T, D, true, false>, nullptr);
+    if (causal && spec && pre) go(attn_fwd_mfma16_kernel<T, D, true, true, false, true>, nullptr);
+    else if (causal) go(attn_fwd_mfma16_kernel<T, D, true, false>, nullptr);
+    else if (spec && pre) go(attn_fwd_mfma16_kernel<T, D, false, true, false, true>, nullptr);
     else if (spec) go(attn_fwd_mfma16_kernel<T, D, false, true>, nullptr);
     else go(attn_fwd_mfma16_kernel<T, D, false, false>, nullptr);
     return check_launch("attn_fwd_mfma16");
@@ -581,19 +655,21 @@ int launch16(const void* q, const void* k, const void* v, void* o, float* lse,
 // may reach 2^12 with float16 weights (largest finite value 65504) and 2^30 with bfloat16 weights,
 // which have float32's exponent range.
 int attn_fwd_mfma16(const void* q, const void* k, const void* v, void* o, float* lse,
-                    int64_t heads, int64_t N, int64_t d, float scale, float thr, int spec, int probe,
+                    int64_t heads, int64_t N, int64_t d, float scale, float thr, int spec, int pre, int probe,
                     int dtype, bool causal, hipStream_t s) {
     const bool sp = spec < 0 ? scale * 1.4426950408889634f * sqrtf((float)d) <= 4.0f : spec != 0;
-    if (thr < 0.f) thr = !sp || causal ? 8.f : dtype == MYFA_BF16 ? 30.f : 12.f;
+    // pre: < 0 = the library's choice (never, in this build), else forced on / off (tuning flavour)
+    const bool pr = sp && pre > 0;
+    if (thr < 0.f) thr = !sp || (causal && !pr) ? 8.f : dtype == MYFA_BF16 ? 30.f : 12.f;
     if (dtype == MYFA_F16 && thr > 15.f) thr = 15.f;
     if (thr > 60.f) thr = 60.f;
     // head dims that are multiples of 8 run on the next build up, the missing columns read as zeros
     if (d >= 8 && d <= 128 && d % 8 == 0) {
         const bool big = d > 64;
-        if (dtype == MYFA_BF16) return big ? launch16<__bf16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, sp, probe, causal, s)
-                                           : launch16<__bf16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, sp, probe, causal, s);
-        if (dtype == MYFA_F16)  return big ? launch16<_Float16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, sp, probe, causal, s)
-                                           : launch16<_Float16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, sp, probe, causal, s);
+        if (dtype == MYFA_BF16) return big ? launch16<__bf16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, probe, causal, s)
+                                           : launch16<__bf16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, probe, causal, s);
+        if (dtype == MYFA_F16)  return big ? launch16<_Float16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, probe, causal, s)
+                                           : launch16<_Float16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, probe, causal, s);
     }
     return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16): head dim %lld is not a multiple of 8 in 8..128", (long long)d);
 }

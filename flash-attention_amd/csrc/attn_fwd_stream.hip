@@ -46,16 +46,6 @@ constexpr int kBKVS = 64;              // keys per tile
 // added to it cannot wrap: fetches from there read zero without touching memory.
 constexpr int kPastEndS = 0x7FFF0000;
 
-// x = KEY > t ? ninf : x, KEY an inline constant (0..64): one compare into VCC, one select.
-template <int KEY>
-__device__ __forceinline__ float hide_past(float x, [[maybe_unused]] int t, [[maybe_unused]] float ninf) {
-    static_assert(KEY >= 0 && KEY <= 64, "inline constant");
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("v_cmp_gt_i32 vcc, %2, %1\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(x) : "v"(t), "n"(KEY), "v"(ninf) : "vcc");
-#endif
-    return x;
-}
-
 // SPEC as in attn_fwd_mfma16_kernel: true = the weights of a tile are formed against the running
 // max as it stands and the tile's maxima are looked for only when a partial row sum passes `lim`;
 // false = the max of every tile, vote on its growth beyond `thr`.

@@ -160,6 +160,16 @@ struct RawMaxOp {
     __device__ __forceinline__ float operator()(float a, float b) const { return vmax2(a, b); }
 };
 
+// x = KEY > t ? ninf : x, KEY an inline constant (0..64): one compare into VCC, one select.
+template <int KEY>
+__device__ __forceinline__ float hide_past(float x, [[maybe_unused]] int t, [[maybe_unused]] float ninf) {
+    static_assert(KEY >= 0 && KEY <= 64, "inline constant");
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_cmp_gt_i32 vcc, %2, %1\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(x) : "v"(t), "n"(KEY), "v"(ninf) : "vcc");
+#endif
+    return x;
+}
+
 // LDS image of a [rows][D] 16-bit tile made of 8-row x 64-byte subtiles (c = 16-byte chunk of
 // the row).  Row reads (ds_read_b128: row = lane & 31, chunk 2*kstep + (lane >> 5)) and
 // transposing reads (ds_read_b64_tr_b16) are both bank-conflict-free on it.

@@ -189,6 +189,30 @@ def softmax(inp, dim=-1, scale=1.0, mask=None, causal=False):
     return out
 
 
+# my_attention at the reference's sizes is a few microseconds of kernel: what the host spends per
+# call shows.  The workspace size the library asks for depends on (n, d) only and is remembered; the
+# workspace itself is kept per (device, stream) and grown when a call needs more -- calls on one
+# stream are ordered, calls on different streams get different buffers -- so a call is one trip
+# into the library and one allocation (the output).
+_ATTN_WS_BYTES = {}
+_ATTN_WS = {}
+
+
+def _attn_workspace(n, d, device, stream):
+    nbytes = _ATTN_WS_BYTES.get((n, d))
+    if nbytes is None:
+        nbytes = _ATTN_WS_BYTES[(n, d)] = int(_lib.lib.myfa_attn_fwd_f32_ws_bytes(n, d))
+    if nbytes <= 0:
+        return None, 0
+    key = (device.index, stream)
+    ws = _ATTN_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if len(_ATTN_WS) > 64:      # streams come and go: do not hold buffers for all of them for ever
+            _ATTN_WS.clear()
+        ws = _ATTN_WS[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+    return ws, nbytes
+
+
 def my_attention(Q, K, V):
     """softmax(Q @ K) @ V for float32 Q:(n,d), K:(d,n) -- already transposed -- and V:(n,d).
 
@@ -206,16 +230,16 @@ def my_attention(Q, K, V):
     _same_device(K, Q, "K"); _same_device(V, Q, "V")
     out = torch.empty_like(Q)
     with _on(Q):
-        # one head has too few query groups for the chip: with a workspace (torch's caching
-        # allocator, stream-ordered) the library also splits the keys over workgroups
-        nbytes = _lib.lib.myfa_attn_fwd_f32_ws_bytes(n, d)
-        if nbytes > 0:
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=Q.device)
+        # one head has too few query groups for the chip: with a workspace the library also splits
+        # the keys over workgroups
+        stream = _stream()
+        ws, nbytes = _attn_workspace(n, d, Q.device, stream)
+        if ws is not None:
             _lib.check(_lib.lib.myfa_attn_fwd_f32_ws(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(),
-                                                     n, d, 1.0, ws.data_ptr(), nbytes, _stream()))
+                                                     n, d, 1.0, ws.data_ptr(), nbytes, stream))
         else:
             _lib.check(_lib.lib.myfa_attn_fwd_f32(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(),
-                                                  n, d, 1.0, _stream()))
+                                                  n, d, 1.0, stream))
     return out
 
 

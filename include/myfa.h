@@ -186,6 +186,13 @@ int myfa_attn_fwd_f32_ws(const float* q, const float* k_t, const float* v, float
  * 1 <= d <= 512, B*H <= 65535 and N*d < 2^31 (myfa_attn_fwd_f32 has the same d and N*d limits;
  * the reference's my_attention has none, but its test shapes end at N = 1025, d = 99).  Outside
  * these limits the call returns MYFA_E_UNSUPPORTED.
+ * `o` with and without `lse` agree to the rounding of the element type, not bit for bit: without
+ * the row statistic, 16-bit launches with d > 64 and scale * log2(e) * sqrt(d) <= 4 multiply q by
+ * scale * log2(e) once, rounded to the element type, instead of scaling every logit in float32
+ * (callers that feed a backward ask for `lse` and get the statistic of the unrounded logits).
+ * The 16-bit launches with 64 < d <= 128 run as many workgroups as the device holds at once, each
+ * working through a share of the (batch, head, query block) problems: the launcher reads the
+ * device's compute-unit count (once per device).
  */
 int myfa_attn_fwd_bhnd(const void* q, const void* k, const void* v, void* o, float* lse,
                        int64_t B, int64_t H, int64_t N, int64_t d,
