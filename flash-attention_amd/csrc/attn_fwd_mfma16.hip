@@ -359,10 +359,16 @@ attn_fwd_mfma16_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
             const float none[2] = {0.f, 0.f};
             // the first tile always looks for its maxima (m is -inf), and so do the masked tiles on the
             // diagonal of a causal launch (nothing is speculated on there)
+            // (The first tile is told apart by a run-time flag the compiler cannot see through: with a
+            // code path of its own for that one call the register allocation of the tile LOOP came out
+            // with 100+ spills.  Its speculative weights are formed and thrown away.)
             bool back = true;
-            if constexpr (!FIRST && SPECULATE) {
+            if constexpr (SPECULATE) {
+                int first_rt = FIRST;
+                asm volatile("" : "+s"(first_rt));
                 weights_pre(none, IC<0>{});
-                back = __builtin_amdgcn_ballot_w64(!(psum[0] <= lim) || !(psum[1] <= lim)) != 0;   // wave-uniform
+                // negated comparisons: a NaN or an infinite sum goes back too
+                back = (__builtin_amdgcn_ballot_w64(!(psum[0] <= lim) || !(psum[1] <= lim)) != 0) | (first_rt != 0);   // wave-uniform
             }
             if (back) {
                 float tmax[2];
