@@ -1,7 +1,8 @@
 // Which kernel runs a 16-bit attention forward (behind myfa_attn_fwd_bhnd[_ex]):
 //   head dims 136..256            attn_fwd_mfma_wide_kernel   (attn_fwd_mfma256.hip)
 //   head dims 72..128             attn_fwd_stream_kernel      (attn_fwd_stream.hip)
-//   head dims 8..64               attn_fwd_mfma16_kernel      (attn_fwd_mfma16.hip)
+//   head dims 8..64, causal       attn_fwd_stream_kernel, one workgroup per CU
+//   head dims 8..64, no mask      attn_fwd_mfma16_kernel      (attn_fwd_mfma16.hip)
 // The tuning flavour of the library can force any build, including the two 32x32x16 ones of
 // attn_fwd_mfma.hip, which only that flavour contains.
 #include <math.h>
@@ -19,7 +20,7 @@ int attn_fwd_mfma16(const void* q, const void* k, const void* v, void* o, float*
                     int64_t heads, int64_t N, int64_t d, float scale, float thr, int spec, int pre, int xflags,
                     int dtype, bool causal, hipStream_t s);
 int attn_fwd_stream(const void* q, const void* k, const void* v, void* o, float* lse,
-                    int64_t heads, int64_t N, int64_t d, float scale, float thr, int spec, int pre, int wgs,
+                    int64_t heads, int64_t N, int64_t d, float scale, float thr, int spec, int pre, int wgs, int occ,
                     int dtype, bool causal, hipStream_t s);
 int attn_fwd_mfma_wide(const void* q, const void* k, const void* v, void* o, float* lse,
                        int64_t heads, int64_t N, int64_t d, float scale, float thr, int dtype, bool causal, hipStream_t s);
@@ -29,7 +30,7 @@ const char* attn_fwd_mfma_kernel_name(int64_t d, [[maybe_unused]] int dtype, [[m
     if (d < 8 || d > 256 || d % 8 != 0) return nullptr;
     if (d > 128) return "attn_fwd_mfma_wide_kernel";
     const int variant = tuning().attn_variant;
-    if (variant == 3 || (variant < 0 && d > 64)) return "attn_fwd_stream_kernel";
+    if (variant == 3 || (variant < 0 && (d > 64 || causal))) return "attn_fwd_stream_kernel";
     if (variant == 2 || variant < 0) return "attn_fwd_mfma16_kernel";
     return variant == 0 && !causal && (d == 64 || d == 128) ? "attn_fwd_mfma_kernel" : "attn_fwd_mfma_pp_kernel";
 }
@@ -51,9 +52,10 @@ int attn_fwd_mfma(const void* q, const void* k, const void* v, void* o, float* l
     // of query blocks as one unbroken stream of tiles: +4..5 % on random operands, +9.5 % in cycles
     // over one workgroup per query block, whose fill and drain leave the CU's matrix cores idle for
     // ~6 % of its life).  Up to 64 it still loses (register spills at 128 registers per lane).
-    if (variant == 3 || (variant < 0 && d > 64))
+    // ... except under the causal mask, where its one-workgroup-per-CU flavour wins by 8-14 %.
+    if (variant == 3 || (variant < 0 && (d > 64 || causal)))
         return attn_fwd_stream(q, k, v, o, lse, heads, N, d, scale, tuning().attn_thr, tuning().attn_spec,
-                               tuning().attn_pre, tuning().attn_wgs, dtype, causal, s);
+                               tuning().attn_pre, tuning().attn_wgs, tuning().attn_occ, dtype, causal, s);
     if (variant == 2 || variant < 0)
         return attn_fwd_mfma16(q, k, v, o, lse, heads, N, d, scale, tuning().attn_thr, tuning().attn_spec,
                                tuning().attn_pre, tuning().attn_xflags, dtype, causal, s);

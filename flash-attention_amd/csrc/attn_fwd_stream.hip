@@ -58,8 +58,9 @@ constexpr int kPastEndS = 0x7FFF0000;
 // whose S was formed beside the previous item's last tile and carries that item's max.
 // The launcher uses it only where logits are small (the regime it picks SPEC in): rounding
 // Q * scale * log2(e) to bfloat16 moves a logit by ~2^-9 of its size, 0.005 base-2 units at most there.
-template <typename T, int D, bool CAUSAL, bool SPEC, bool PRE = false>
-__global__ void __launch_bounds__(kThreadsS, D == 64 ? 4 : 2)
+// WIDE (D = 64 only): one workgroup per CU with 256 registers per lane instead of two with 128.
+template <typename T, int D, bool CAUSAL, bool SPEC, bool PRE = false, bool WIDE = false>
+__global__ void __launch_bounds__(kThreadsS, D == 64 && !WIDE ? 4 : 2)
 attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* __restrict__ Vg,
                        T* __restrict__ Og, float* __restrict__ LSEg, int N, int nqblk, int hp, int nunits,
                        float sl2, float thr, float lim, int gd) {
@@ -708,7 +709,7 @@ int cu_count_current() {
 
 template <typename T, int D>
 int launch_stream(const void* q, const void* k, const void* v, void* o, float* lse,
-                  int64_t heads, int64_t N, int64_t d, float scale, float thr, bool spec, bool pre, bool causal, int wgs, hipStream_t s) {
+                  int64_t heads, int64_t N, int64_t d, float scale, float thr, bool spec, bool pre, bool causal, int wgs, bool wide, hipStream_t s) {
     if (N * d * 2 >= (int64_t)kPastEndS) return fail(MYFA_E_UNSUPPORTED, "attention: N*d=%lld per head too large", (long long)(N * d));
     const int64_t nqblk = cdiv(N, kBQS);
     // units of work: query blocks, or under the causal mask pairs of mirrored query blocks of a head
@@ -721,7 +722,7 @@ int launch_stream(const void* q, const void* k, const void* v, void* o, float* l
     if (cap <= 0) {
         const int cus = cu_count_current();
         if (cus == 0) return MYFA_E_DEVICE;
-        cap = (int64_t)cus * (D == 64 ? 2 : 1);
+        cap = (int64_t)cus * (D == 64 && !wide ? 2 : 1);
     }
     const int64_t grid = nunits < cap ? nunits : cap;
     const float sl2 = scale * 1.4426950408889634f;
@@ -731,6 +732,16 @@ int launch_stream(const void* q, const void* k, const void* v, void* o, float* l
                       static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
                       static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)hp, (int)nunits, sl2, thr, lim, (int)d);
     };
+    if constexpr (D == 64) {
+        if (wide) {
+            if (causal && spec && pre) go(attn_fwd_stream_kernel<T, D, true, true, true, true>);
+            else if (causal) go(attn_fwd_stream_kernel<T, D, true, false, false, true>);
+            else if (spec && pre) go(attn_fwd_stream_kernel<T, D, false, true, true, true>);
+            else if (spec) go(attn_fwd_stream_kernel<T, D, false, true, false, true>);
+            else go(attn_fwd_stream_kernel<T, D, false, false, false, true>);
+            return check_launch("attn_fwd_stream");
+        }
+    }
     if (causal && spec && pre) go(attn_fwd_stream_kernel<T, D, true, true, true>);
     else if (causal) go(attn_fwd_stream_kernel<T, D, true, false>);
     else if (spec && pre) go(attn_fwd_stream_kernel<T, D, false, true, true>);
@@ -743,11 +754,16 @@ int launch_stream(const void* q, const void* k, const void* v, void* o, float* l
 
 // dtype: MYFA_F16 or MYFA_BF16; d: a multiple of 8 in 8..128; heads = B*H.
 // spec, thr: as attn_fwd_mfma16 (attn_fwd_mfma16.hip): < 0 = the library's choice.
-// wgs: workgroups in the grid; <= 0 = as many as the chip holds at once.
+// wgs: workgroups in the grid; <= 0 = as many as the chip holds at once.  occ: see below.
 int attn_fwd_stream(const void* q, const void* k, const void* v, void* o, float* lse,
-                    int64_t heads, int64_t N, int64_t d, float scale, float thr, int spec, int pre, int wgs,
+                    int64_t heads, int64_t N, int64_t d, float scale, float thr, int spec, int pre, int wgs, int occ,
                     int dtype, bool causal, hipStream_t s) {
     if (heads <= 0 || N <= 0) return MYFA_OK;
+    // occ (head dims up to 64): 1 = one workgroup per CU with 256 registers per lane, 2 = two with 128,
+    // else the library's choice: one.  (Two spill 40-110 vector registers; one, under the causal mask,
+    // beats the one-block-per-workgroup kernel by 8-14 % at B4 H32 N4096 d64 and 10 % at B8 H16 N1024
+    // d64, and without the mask loses 6-9 % to it -- the dispatch sends only causal launches here.)
+    const bool wide = d <= 64 && occ != 2;
     const bool sp = spec < 0 ? scale * 1.4426950408889634f * sqrtf((float)d) <= 4.0f : spec != 0;
     // pre: < 0 = the library's choice: wherever the speculative build runs and no row statistic is
     // asked for (inference).  The rounding of Q * scale * log2(e) moves a logit by ~2^-9 of its size --
@@ -755,18 +771,19 @@ int attn_fwd_stream(const void* q, const void* k, const void* v, void* o, float*
     // but the row log-sum-exp moves with its largest logits (0.01 for a logit of 35), and a backward
     // that recomputes the logits from the unscaled Q wants the statistic of exactly those logits.
     // Else forced on / off (tuning flavour).
-    // (Head dims up to 64: never by itself -- that build already spills registers and loses a third with it.)
-    const bool pr = sp && (pre < 0 ? lse == nullptr && d > 64 : pre != 0);
+    // (Head dims up to 64 with two workgroups per CU: never by itself -- that build already spills
+    // registers and loses a third with it.)
+    const bool pr = sp && (pre < 0 ? lse == nullptr && (d > 64 || wide) : pre != 0);
     if (thr < 0.f) thr = !sp || (causal && !pr) ? 8.f : dtype == MYFA_BF16 ? 30.f : 12.f;
     if (dtype == MYFA_F16 && thr > 15.f) thr = 15.f;
     if (thr > 60.f) thr = 60.f;
     // head dims that are multiples of 8 run on the next build up, the missing columns read as zeros
     if (d >= 8 && d <= 128 && d % 8 == 0) {
         const bool big = d > 64;
-        if (dtype == MYFA_BF16) return big ? launch_stream<__bf16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, causal, wgs, s)
-                                           : launch_stream<__bf16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, causal, wgs, s);
-        if (dtype == MYFA_F16)  return big ? launch_stream<_Float16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, causal, wgs, s)
-                                           : launch_stream<_Float16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, causal, wgs, s);
+        if (dtype == MYFA_BF16) return big ? launch_stream<__bf16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, causal, wgs, wide, s)
+                                           : launch_stream<__bf16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, causal, wgs, wide, s);
+        if (dtype == MYFA_F16)  return big ? launch_stream<_Float16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, causal, wgs, wide, s)
+                                           : launch_stream<_Float16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, causal, wgs, wide, s);
     }
     return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16): head dim %lld is not a multiple of 8 in 8..128", (long long)d);
 }

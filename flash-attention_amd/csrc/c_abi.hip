@@ -243,6 +243,7 @@ int myfa_tuning_set(const char* key, double value) {
     else if (k == "attn_xflags") t.attn_xflags = (int)value;
     else if (k == "attn_wgs") t.attn_wgs = (int)value;
     else if (k == "attn_pre") t.attn_pre = (int)value;
+    else if (k == "attn_occ") t.attn_occ = (int)value;
     else if (k == "attn_f32_wgs") t.attn_f32_wgs = (int)value;
     else if (k == "matmul_block") t.matmul_block = (int)value;
     else if (k == "matmul_ksplit") t.matmul_ksplit = (int)value;

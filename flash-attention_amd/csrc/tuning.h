@@ -31,6 +31,9 @@ struct Tuning {
     // resident-workgroup build, speculative softmax: 1 = Q pre-multiplied by scale * log2(e) and the
     // running max folded into the accumulators' start value, 0 = not, -1 = the library's choice
     int attn_pre = -1;
+    // resident-workgroup build, head dims up to 64: 1 = one workgroup per CU (256 registers per lane),
+    // else two (128)
+    int attn_occ = 0;
     // resident-workgroup build: workgroups in the grid (0 = as many as the chip holds at once)
     int attn_wgs = 0;
     // device buffer for the stamped (cycle-counting) diagnostic build, 24 u64 per workgroup

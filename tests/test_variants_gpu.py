@@ -117,21 +117,22 @@ def test_mfma_shapes_vs_oracle(tuned, variant, spec, causal, dtype, shape):
     assert _maxdiff(lse.cpu().numpy(), ref_cpu.attention_lse(qr, kr, scale=scale, causal=causal)) <= 1e-3
 
 
-@pytest.mark.parametrize("wgs", [1, 3, 8, 11, 0])
+@pytest.mark.parametrize("wgs,occ", [(1, 0), (3, 0), (8, 2), (11, 0), (0, 0), (0, 2)])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("shape,dtype", [
     ((2, 3, 64, 64), torch.float16), ((1, 5, 40, 128), torch.bfloat16), ((2, 2, 700, 128), torch.bfloat16),
     ((1, 3, 1300, 64), torch.float16), ((3, 2, 257, 128), torch.float16), ((1, 4, 130, 64), torch.bfloat16),
     ((2, 2, 1, 128), torch.bfloat16), ((1, 2, 520, 72), torch.bfloat16),
 ])
-def test_resident_workgroups_stream_through_their_items(tuned, wgs, causal, shape, dtype):
+def test_resident_workgroups_stream_through_their_items(tuned, wgs, occ, causal, shape, dtype):
     """The resident-workgroup build with FEWER workgroups than query blocks: every workgroup works
     through several (head, query block) items back to back -- rings, Q fragments and the running
     softmax state turn over between items, also for items of a single tile (N <= 64) and under the
-    causal mask, where items differ in length."""
+    causal mask, where items differ in length.  occ = 2: head dims up to 64 with two workgroups per CU
+    (128 registers per lane) instead of the library's one."""
     B, H, N, d = shape
     scale = d ** -0.5
-    tuned.set(attn_variant=3, attn_wgs=wgs)
+    tuned.set(attn_variant=3, attn_wgs=wgs, attn_occ=occ)
     torch.manual_seed(3)
     q, k, v = (torch.randn(B, H, N, d, dtype=torch.float32) for _ in range(3))
     qd, kd, vd = (x.cuda().to(dtype) for x in (q, k, v))
