@@ -200,8 +200,41 @@ def profiled_traffic():
     return None
 
 
+def profiled_softmax_traffic():
+    """HBM bytes per launch of the row-softmax kernel at n = 8192 and 32768 from the newest committed
+    counter file of the other kernels (profiles/rNN_other_kernels_pmc.txt, written by
+    tools/pmc_round3.sh on a GPU box): sections `=== softmax<n> ===`, reads = TCC_EA0_RDREQ x 128 B,
+    writes = TCC_EA0_WRREQ x 64 B (all of them 64-byte requests there).  {} when there is no such file."""
+    import glob
+    import re
+    out = {}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_other_kernels_pmc.txt")))
+    if not files:
+        return out
+    n, vals = None, {}
+
+    def close():
+        if n is not None and "TCC_EA0_RDREQ_sum" in vals and "TCC_EA0_WRREQ_sum" in vals:
+            out[n] = {"bytes": vals["TCC_EA0_RDREQ_sum"] * 128.0 + vals["TCC_EA0_WRREQ_sum"] * 64.0,
+                      "source": os.path.relpath(files[-1], ROOT)}
+    with open(files[-1]) as fh:
+        for line in fh:
+            m = re.match(r"^=== (\w+) ===", line)
+            if m:
+                close()
+                sm = re.match(r"^softmax(\d+)$", m.group(1))
+                n, vals = (int(sm.group(1)) if sm else None), {}
+                continue
+            m = re.match(r"^(TCC_EA0_\w+)\s+([0-9.]+)", line)
+            if m and n is not None:
+                vals[m.group(1)] = float(m.group(2))
+    close()
+    return out
+
+
 def bench_softmax_sweep(mfa, iters=20):
     res = []
+    traffic = profiled_softmax_traffic()
     for n in (4096, 8192, 16384, 32768):
         nbuf = 3 if n <= 8192 else 1      # rotate inputs larger than the 256 MiB Infinity Cache
         xs = [torch.randn(n, n, dtype=torch.float32, device="cuda") for _ in range(nbuf)]
@@ -217,7 +250,11 @@ def bench_softmax_sweep(mfa, iters=20):
         ms = sorted(a.elapsed_time(b) for a, b in ev)
         med = ms[len(ms) // 2]
         gbs = 2.0 * n * n * 4 / (med * 1e-3) / 1e9
-        res.append({"n": n, "us": round(med * 1e3, 2), "GB/s": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
+        res.append({"n": n, "us": round(med * 1e3, 2), "GB/s": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                    # HBM bytes per launch from the committed counter passes of this size (None where none
+                    # was taken), beside the algorithmic 8 B/element
+                    "traffic": traffic[n]["bytes"] if n in traffic else None, "algorithmic_bytes": 2.0 * n * n * 4,
+                    "traffic_source": traffic[n]["source"] if n in traffic else None})
         del xs, out
         torch.cuda.empty_cache()
     return res
