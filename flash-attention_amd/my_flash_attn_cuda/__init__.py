@@ -302,12 +302,14 @@ def attn_fwd_kernel_name(d, dtype, causal=False):
     return name.decode() if name else None
 
 
-BWD_MAX_HEAD_DIM = 128
+BWD_MAX_HEAD_DIM = 256
+BWD_NATIVE_HEAD_DIMS = (64, 128, 192, 256)   # what the backward kernels are built for
 
 
 def flash_attn_bwd(dout, q, k, v, out, lse, scale=1.0, causal=False):
     """Gradients (dq, dk, dv) of flash_attn_fwd for float16 / bfloat16 (B, H, N, d) tensors,
-    d <= 128 (64 and 128 natively, smaller ones through zero-padded copies).  `out` and `lse` are the forward's results (return_lse=True), `dout` the
+    d <= 256 (64, 128, 192 and 256 natively, the others through copies zero-padded to the next of
+    those).  `out` and `lse` are the forward's results (return_lse=True), `dout` the
     gradient of `out`.  The reference has no backward; this is the derivative of the forward
     it sketches (csrc/my_flash_attn/flash_attention.cu:23-69)."""
     for t, name in ((dout, "dout"), (q, "q"), (k, "k"), (v, "v"), (out, "out"), (lse, "lse")):
@@ -322,12 +324,12 @@ def flash_attn_bwd(dout, q, k, v, out, lse, scale=1.0, causal=False):
     B, H, N, d = q.shape
     if d > BWD_MAX_HEAD_DIM:
         raise RuntimeError(f"flash_attn_bwd supports head dims up to {BWD_MAX_HEAD_DIM}, got {d} "
-                           "(the forward runs wider heads; their backward does not exist)")
+                           "(float32 runs wider heads forward; a backward for them does not exist)")
     if lse.dtype != torch.float32 or tuple(lse.shape) != (B, H, N):
         raise RuntimeError("lse must be the float32 (B, H, N) tensor returned by flash_attn_fwd")
-    if d not in (64, 128) and 0 < d < 128:
-        # the backward kernels exist for d = 64 and 128: zero columns up to there change nothing
-        pad = (64 if d < 64 else 128) - d
+    if d not in BWD_NATIVE_HEAD_DIMS and d > 0:
+        # zero columns up to the next head dim the kernels are built for change nothing
+        pad = min(n for n in BWD_NATIVE_HEAD_DIMS if n > d) - d
         padded = [torch.nn.functional.pad(t, (0, pad)) for t in (dout, q, k, v, out)]
         return tuple(g[..., :d].contiguous() for g in flash_attn_bwd(*padded, lse, scale=scale, causal=causal))
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
@@ -357,9 +359,9 @@ def flash_attn_bwd_into(dout, q, k, v, out, lse, dq, dk, dv, scale=1.0, causal=F
     if q.dtype not in (torch.float16, torch.bfloat16):
         raise RuntimeError(f"flash_attn_bwd supports float16 and bfloat16, got {q.dtype}")
     B, H, N, d = q.shape
-    if d not in (64, 128):
-        raise RuntimeError(f"flash_attn_bwd_into supports head dims 64 and 128, got {d} "
-                           "(flash_attn_bwd pads smaller ones through copies, which this entry may not make)")
+    if d not in BWD_NATIVE_HEAD_DIMS:
+        raise RuntimeError(f"flash_attn_bwd_into supports head dims 64, 128, 192 and 256, got {d} "
+                           "(flash_attn_bwd pads the others through copies, which this entry may not make)")
     if lse.dtype != torch.float32 or tuple(lse.shape) != (B, H, N):
         raise RuntimeError("lse must be the float32 (B, H, N) tensor returned by flash_attn_fwd")
     with _on(q):
@@ -389,9 +391,9 @@ class _FlashAttnFunc(torch.autograd.Function):
 
 
 def flash_attn_func(q, k, v, scale=1.0, causal=False):
-    """flash_attn_fwd with autograd support: float16 / bfloat16, head dims up to 128 (64 and 128
-    natively, the others through zero-padded copies in the backward).  Wider heads and float32 have
-    a forward only and are refused here, before any work is done."""
+    """flash_attn_fwd with autograd support: float16 / bfloat16, head dims up to 256 (64, 128, 192
+    and 256 natively, the others through zero-padded copies in the backward).  float32 has a
+    forward only and is refused here, before any work is done."""
     return _FlashAttnFunc.apply(q, k, v, scale, causal)
 
 

@@ -222,7 +222,8 @@ int myfa_attn_fwd_bhnd_ex(const void* q, const void* k, const void* v, void* o, 
 const char* myfa_attn_fwd_bhnd_kernel(int64_t d, int dtype, int flags);
 
 /*
- * Backward of myfa_attn_fwd_bhnd_ex for MYFA_F16 / MYFA_BF16, d in {64, 128}:
+ * Backward of myfa_attn_fwd_bhnd_ex for MYFA_F16 / MYFA_BF16, d in {64, 128, 192, 256}
+ * (192 and 256: four-wave workgroups on 32-row tiles, dK and dV in separate launches):
  * given the forward's inputs, its output `o`, its row log-sum-exp `lse` and the
  * gradient `dout` of the output, writes dq, dk, dv (same shape and dtype as q, k, v).
  * `delta_ws` is a float32 workspace of 2*B*H*N elements provided by the caller (it

@@ -110,6 +110,71 @@ def test_bwd_vs_oracle(mfa, shape, dtype, causal):
         _check_elementwise(got, ref, q, k, v, do, dtype, scale, causal)
 
 
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [
+    (1, 1, 1, 256), (1, 2, 31, 256), (1, 2, 200, 256), (2, 2, 513, 256), (1, 1, 1024, 256), (1, 3, 129, 192),
+    (1, 1, 640, 192), (1, 2, 300, 160), (1, 1, 257, 136), (1, 1, 96, 248),
+])
+def test_bwd_wide_heads_vs_oracle(mfa, shape, dtype, causal):
+    """Head dims above 128: the four-wave build for 192 and 256 columns (others zero-padded up to
+    those), ragged lengths on both sides of its 128-row blocks and 32-row tiles."""
+    B, H, N, d = shape
+    scale = d ** -0.5
+    torch.manual_seed(5)
+    q, k, v, do = (torch.randn(B, H, N, d, dtype=torch.float32) for _ in range(4))
+    got = _run(mfa, q, k, v, do, dtype, scale, causal)
+    ref = ref_cpu.attention_bwd_bhnd(*(_rounded(x, dtype) for x in (q, k, v, do)), scale=scale, causal=causal)
+    for nm, a, b in zip(("dq", "dk", "dv"), got, ref):
+        assert a.shape == shape and a.dtype == dtype
+        assert bool(torch.isfinite(a.float()).all()), nm
+        assert _rel(a.float().cpu().numpy(), b) <= REL, nm
+    if N > 1:
+        _check_elementwise(got, ref, q, k, v, do, dtype, scale, causal)
+
+
+def test_bwd_wide_heads_unscaled_logits(mfa):
+    """scale = 1.0 at d = 256: logits with a standard deviation of 16."""
+    B, H, N, d = 1, 2, 384, 256
+    torch.manual_seed(6)
+    q, k, v, do = (torch.randn(B, H, N, d, dtype=torch.float32) for _ in range(4))
+    got = _run(mfa, q, k, v, do, torch.bfloat16, 1.0, True)
+    ref = ref_cpu.attention_bwd_bhnd(*(_rounded(x, torch.bfloat16) for x in (q, k, v, do)), scale=1.0, causal=True)
+    for nm, a, b in zip(("dq", "dk", "dv"), got, ref):
+        assert _rel(a.float().cpu().numpy(), b) <= REL, nm
+    _check_elementwise(got, ref, q, k, v, do, torch.bfloat16, 1.0, True)
+
+
+@pytest.mark.parametrize("d", [192, 256])
+def test_autograd_function_wide_heads(mfa, d):
+    """flash_attn_func is differentiable for head dims 192 and 256: against autograd of PyTorch's
+    SDPA in float64 on the same (rounded) inputs."""
+    B, H, N = 1, 3, 320
+    torch.manual_seed(7)
+    q, k, v = (torch.randn(B, H, N, d, device="cuda", dtype=torch.float16, requires_grad=True) for _ in range(3))
+    do = torch.randn(B, H, N, d, device="cuda", dtype=torch.float16)
+    out = mfa.flash_attn_func(q, k, v, scale=d ** -0.5, causal=False)
+    out.backward(do)
+    qf, kf, vf = (x.detach().double().cpu().requires_grad_(True) for x in (q, k, v))
+    ref = torch.nn.functional.scaled_dot_product_attention(qf, kf, vf, scale=d ** -0.5)
+    ref.backward(do.double().cpu())
+    assert float((out.detach().double().cpu() - ref.detach()).abs().max()) <= 2e-2
+    for a, b in ((q.grad, qf.grad), (k.grad, kf.grad), (v.grad, vf.grad)):
+        assert _rel(a.float().cpu().numpy(), b.numpy()) <= REL
+
+
+def test_bwd_into_wide_head(mfa):
+    """The allocation-free entry serves the same head dims (same kernels: equal bit for bit)."""
+    B, H, N, d = 1, 2, 200, 256
+    torch.manual_seed(8)
+    q, k, v, do = (torch.randn(B, H, N, d, dtype=torch.bfloat16, device="cuda") for _ in range(4))
+    out, lse = mfa.flash_attn_fwd(q, k, v, scale=d ** -0.5, return_lse=True)
+    want = mfa.flash_attn_bwd(do, q, k, v, out, lse, scale=d ** -0.5)
+    got = mfa.flash_attn_bwd_into(do, q, k, v, out, lse, *(torch.empty_like(q) for _ in range(3)), scale=d ** -0.5)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("shape,causal", [((1, 2, 300, 64), False), ((1, 2, 512, 128), False), ((2, 1, 700, 128), True)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_bwd_unscaled_logits(mfa, shape, causal, dtype):
@@ -196,3 +261,6 @@ def test_bwd_errors(mfa):
         mfa.flash_attn_bwd(qb, qb, qb, qb, qb, lse[:, :, :32])
     with pytest.raises(RuntimeError, match="Wrong sizes"):
         mfa.flash_attn_bwd(qb, qb, qb[:, :, :32], qb, qb, lse)
+    wide = torch.randn(1, 1, 64, 264, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="head dims up to 256"):
+        mfa.flash_attn_bwd(wide, wide, wide, wide, wide, lse)
