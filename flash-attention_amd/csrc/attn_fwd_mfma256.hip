@@ -2,45 +2,35 @@
 //
 //     O[b,h] = softmax(scale * Q[b,h] K[b,h]^T) V[b,h]      Q,K,V,O: [B,H,N,d], d a multiple of 8 in 136..256
 //
-// Same math and register choreography as attn_fwd_mfma.hip (the online-softmax recurrence of
-// tests/test_flash_attn.py:82-93 on v_mfma_f32_32x32x16, S^T = K Q^T so that a query's logits sit in
-// one lane pair, O^T = V^T P^T with the transposing LDS read); what differs is the budget.  At 256
-// columns a wave's O^T tile alone is 128 accumulator registers and its Q fragments 64 more, so a
-// wave needs the whole register file of its SIMD:
+// Same math as the narrower builds (the online-softmax recurrence of tests/test_flash_attn.py:82-93
+// on v_mfma_f32_32x32x16, S^T = K Q^T so that a query's logits sit in one lane pair, O^T = V^T P^T
+// with the transposing LDS read); what differs is the budget.  At 256 columns a wave's O^T tile
+// alone is 128 accumulator registers and its Q fragments 64 more, so a wave needs the whole
+// register file of its SIMD:
 //   workgroup = 4 waves = 128 query rows, one wave per SIMD (512 registers), wave w owns rows 32w..32w+31;
-//   K/V tiles of 64 keys x 256 columns (32 KiB each), double-buffered in LDS (128 KiB), staged
-//   through registers one tile ahead (buffer loads: rows past N and columns past d read as zeros,
-//   so any multiple of 8 up to 256 runs on this build), one barrier per tile;
-//   matrix and vector work of a tile run in the one wave, in the compiler's interleaving.  A tile is
-//   64 MFMAs (2048 cycles) against ~250 vector instructions, so the matrix pipe stays the larger
-//   share without a second wave to overlap with.
+//   K / V tiles of 32 keys (16 KiB at 256 columns) go HBM/L2 -> LDS directly (buffer_load ... lds:
+//   rows past N and columns past d read as zeros, so any multiple of 8 up to the build's width
+//   runs on it), three LDS buffers per tensor, the fetch two tiles ahead, one barrier per tile;
+//   with nobody else on the SIMD the wave overlaps its own work: an iteration issues
+//   S(t+1) = K(t+1) Q^T, looks for the tile's maxima, and then runs the weights of tile t+1 (exp2,
+//   row sum) one element at a time in the shadow of the MFMAs of O^T += V(t)^T P(t)^T.
 // The running max moves only in a tile where some row's max grew by more than `thr` (log2 units;
-// P may reach 2^thr), which keeps the 128-register rescale of O^T out of most tiles.
+// P may reach 2^thr), which keeps the rescale of O^T out of most tiles; when it moves, O^T is
+// rescaled behind the tile's last MFMA (P(t) was formed against the old max, like all of O^T).
+// Builds: 192 and 256 columns.
 #include "attn_mfma_common.h"
 
 namespace myfa {
 namespace {
 
-constexpr int kWavesW = 4;
-constexpr int kThreadsW = kWavesW * 64;
-constexpr int kBQW = kWavesW * 32;   // query rows per workgroup
-constexpr int kBKVW = 64;            // keys per tile
-constexpr int kDW = 256;             // columns of the build
+constexpr int kThreadsW = 256;       // 4 waves
+constexpr int kBQW = 128;            // query rows per workgroup
+constexpr int kBKVW = 32;            // keys per tile
 // A buffer offset no tensor reaches (the launcher keeps a head below it) and that a tile offset
 // added to it cannot wrap: fetches from there read zero without touching memory.
 constexpr int kPastEndW = 0x7FFF0000;
 
-// LDS images of a [64][256] tile, row-major with the 16-byte chunk index XOR-swizzled inside each
-// half row: K for row reads (ds_read_b128, 32 rows x 2 chunks per instruction), V for the
-// transposing reads (ds_read_b64_tr_b16).
-__device__ __forceinline__ int k_off_w(int row, int ch) {
-    return row * (2 * kDW) + (((ch & 16) | ((ch & 15) ^ (row & 15))) << 4);
-}
-__device__ __forceinline__ int v_off_w(int row, int ch) {
-    return row * (2 * kDW) + (((ch & 16) | ((ch & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3)))) << 4);
-}
-
-template <typename T, bool CAUSAL>
+template <typename T, int D, bool CAUSAL>
 __global__ void __launch_bounds__(kThreadsW, 1)
 attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* __restrict__ Vg,
                           T* __restrict__ Og, float* __restrict__ LSEg, int N, int nqblk, int nwg,
@@ -48,14 +38,14 @@ attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, co
     using M = Mma<T>;
     using vec8 = typename M::vec8;
     using vec4 = typename M::vec4;
-    constexpr int D = kDW;
-    constexpr int CPR = D / 8;                    // 16-byte chunks per row
-    constexpr int TILE_B = kBKVW * D * 2;         // bytes per K (or V) tile
+    constexpr int TR = kBKVW;
+    constexpr int TILE_B = TR * D * 2;            // bytes per K (or V) tile image
     constexpr int KS = D / 16;                    // k-steps of S^T = K Q^T
     constexpr int DB = D / 32;                    // 32-row blocks of O^T
-    constexpr int LPT = kBKVW * CPR / kThreadsW;  // 16-byte loads per thread per tile
+    constexpr int LPT = TR * (D / 8) / kThreadsW; // 1-KiB pieces per wave and tile
+    static_assert(LPT * kThreadsW == TR * (D / 8), "whole 1-KiB pieces per wave");
 
-    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_B];   // K0 K1 V0 V1
+    __shared__ __attribute__((aligned(16))) char lds[6 * TILE_B];   // K0 K1 K2 V0 V1 V2
 
     // Workgroups that share one head's K/V get consecutive logical ids, and each XCD
     // (blockIdx % 8 under round-robin dispatch) a contiguous range of them.  Speed only.
@@ -69,17 +59,15 @@ attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, co
     const int qblk = CAUSAL ? nqblk - 1 - (lid - head * nqblk) : lid - head * nqblk;
     const int q0 = qblk * kBQW;
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
 
     // gd <= D is the head dim in memory: rows are gd elements apart, chunks past it read as zeros
     const size_t hoff = (size_t)head * (size_t)N * gd;
     const unsigned head_bytes = (unsigned)N * (unsigned)gd * 2u;
-    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc((void*)(Qg + hoff), 0, head_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)(Kg + hoff), 0, head_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(Vg + hoff), 0, head_bytes, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc((void*)(Qg + hoff), 0, head_bytes, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)(Kg + hoff), 0, head_bytes, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(Vg + hoff), 0, head_bytes, 0x00020000);
 
     // ---- Q^T fragments: lane (r, h) holds Q[row][16ks + 8h .. +7] for ks = 0..KS-1 (rows past N: zeros)
     const int qrow = q0 + wave * 32 + r;
@@ -87,29 +75,58 @@ attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, co
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const int ch = 2 * ks + h;
-        const int off = ch * 8 < gd ? qrow * gd * 2 + ch * 16 : kPastEndW;
+        [[maybe_unused]] const int off = ch * 8 < gd ? qrow * gd * 2 + ch * 16 : kPastEndW;
+#if defined(__HIP_DEVICE_COMPILE__)
         qf[ks] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(qrs, off, 0, 0));
+#endif
     }
 
-    // ---- staging of one K/V tile through registers: thread -> chunk (tid & 31) of rows (tid >> 5) + 8i
-    const int st_row = tid >> 5, st_ch = tid & 31;
-    const int st_off = st_ch * 8 < gd ? st_row * gd * 2 + st_ch * 16 : kPastEndW;
-    u32x4 kst[LPT], vst[LPT];
-    auto stage_load = [&](int kv0) {
-        const int soff = kv0 * gd * 2;            // (past the last tile: past the end of the head, zeros)
+    // ---- K / V tiles: piece i of wave w is image bytes 1024 (w LPT + i) .. + 1023, lane L at + 16 L,
+    // so the image (attn_mfma_common.h) is produced by choosing each lane's SOURCE chunk
+    int goff[LPT];
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            kst[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, st_off + 8 * i * gd * 2, soff, 0));
-            vst[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, st_off + 8 * i * gd * 2, soff, 0));
-        }
+    for (int i = 0; i < LPT; ++i) {
+        const int u = 64 * (wave * LPT + i) + lane;
+        const int grp8 = u / D, within = u % D;          // 16-byte units: D of them per 8-row group
+        const int row = 8 * grp8 + ((within & 31) >> 2);
+        const int ch = 4 * (within >> 5) + ((within & 3) ^ ((row >> 2) & 3));
+        goff[i] = ch * 8 < gd ? (row * gd + ch * 8) * 2 : kPastEndW;
+    }
+    const int tile_stride = TR * gd * 2;          // bytes of a tile in memory
+    // piece p of a fetch (p < 2 LPT): even p this wave's piece p/2 of K tile `kt` into K buffer `kbuf`,
+    // odd p that of V tile `vt` into V buffer `vbuf`.  (The host pass of hipcc silently drops a
+    // kernel whose body names this builtin.)
+    auto fetch_piece = [&](int kt, int kbuf, int vt, int vbuf, int p) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if ((p & 1) == 0)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_void*)(lds + kbuf * TILE_B + 1024 * (wave * LPT + p / 2)),
+                                                     16, goff[p / 2], kt * tile_stride, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_void*)(lds + (3 + vbuf) * TILE_B + 1024 * (wave * LPT + p / 2)),
+                                                     16, goff[p / 2], vt * tile_stride, 0, 0);
+#endif
     };
-    auto stage_write = [&](int buf) {
+
+    // ---- fragment addresses (per-lane bases; everything else is an immediate)
+    const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
+    int rbase[2], tbase[2];
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const int row = st_row + 8 * i;
-            *reinterpret_cast<u32x4*>(lds + buf * TILE_B + k_off_w(row, st_ch)) = kst[i];
-            *reinterpret_cast<u32x4*>(lds + (2 + buf) * TILE_B + v_off_w(row, st_ch)) = vst[i];
-        }
+    for (int e = 0; e < 2; ++e) {
+        rbase[e] = 16 * D * (r >> 3) + 64 * (r & 7) + 16 * ((2 * e + h) ^ ((r >> 2) & 3));
+        tbase[e] = 64 * (4 * h + tq) + 16 * ((2 * tg1 + (tp >> 1)) ^ (2 * e + h)) + 8 * (tp & 1) + 16 * D * e;
+    }
+    auto k_frag = [&](const char* Kb, int ks) __attribute__((always_inline)) -> s16x8 {
+        return *reinterpret_cast<const s16x8*>(Kb + rbase[ks & 1] + 512 * (ks >> 1));
+    };
+    auto v_frag = [&](const char* Vb, int i) __attribute__((always_inline)) -> s16x8 {
+        const int st = i / DB, db = i % DB;       // 16 keys x 32 columns
+        const int imm = 16 * D * 2 * st + 512 * db;
+        const s16x4 lo = lds_read_tr(Vb + tbase[0] + imm);
+        const s16x4 hi = lds_read_tr(Vb + tbase[1] + imm);
+        s16x8 a;
+        a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
+        a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
+        return a;
     };
 
     f32x16 o[DB];
@@ -120,121 +137,153 @@ attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, co
     float m = -INFINITY;   // running (deferred) row max of scale*log2(e)*S
     float l = 0.f;         // this lane half's share of the running row sum
 
-    const int ntiles_all = (N + kBKVW - 1) / kBKVW;
-    const int ntiles = CAUSAL ? min(ntiles_all, (q0 + kBQW) / kBKVW) : ntiles_all;
+    const int T_all = (N + TR - 1) / TR;
+    const int ntiles = CAUSAL ? min(T_all, (q0 + kBQW) / TR) : T_all;
     // the last key a row may see: tile 0 always holds key 0, which every row sees
     const int key_limit = CAUSAL ? min(N - 1, qrow) : N - 1;
-    stage_load(0);
-    stage_write(0);
+    auto tile_or_end = [&](int t) __attribute__((always_inline)) { return t < ntiles ? t : T_all; };   // past the end: zeros
+
+    // prologue: K(0), V(0), K(1) -- and V(1), K(2) in flight behind them
+#pragma unroll
+    for (int p = 0; p < 2 * LPT; ++p) fetch_piece(0, 0, 0, 0, p);
+#pragma unroll
+    for (int p = 0; p < 2 * LPT; ++p) fetch_piece(tile_or_end(1), 1, tile_or_end(1), 1, p);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2 * LPT; p += 2) fetch_piece(tile_or_end(2), 2, 0, 0, p);      // K(2) only
 
-    // lane-constant parts of the transposing-read address
-    const int tq = (lane & 15) >> 2, tp = lane & 3, tg1 = (lane >> 4) & 1;
+    constexpr int FW = 4;                          // LDS fragments requested ahead of the MFMA stream
+    constexpr int NPV = 2 * DB;                    // MFMAs of O^T += V^T P^T per tile
+    constexpr int EP = (16 + NPV - 1) / NPV;       // weights formed per MFMA of that stream
 
-    for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
-        const int kv0 = t * kBKVW;
-        stage_load(kv0 + kBKVW);
-
-        const char* Kb = lds + buf * TILE_B;
-        const char* Vb = lds + (2 + buf) * TILE_B;
-
-        // ---- S^T = K Q^T : 2 key blocks x KS k-steps.  One wave per SIMD has nobody to hide an LDS
-        // read's latency behind, so fragments are read eight at a time, a batch ahead of the MFMAs
-        // that consume them.
-        f32x16 s[2];
-        constexpr int KB = 8;                     // fragments per batch
-        s16x8 ka[2][KB];
+    f32x16 s;
+    // S^T of one tile: key (i & 3) + 8 (i >> 2) + 4 h of the tile in register i
+    auto s_stream = [&](const char* Kb) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < KB; ++j) ka[0][j] = *reinterpret_cast<const s16x8*>(Kb + k_off_w(r, 2 * j + h));
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+        s16x8 win[FW];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int i = 0; i < FW; ++i) win[i] = k_frag(Kb, i);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+        for (int i = 0; i < KS; ++i) {
+            const s16x8 a = win[i % FW];
+            s = M::run(a, qf[i], s);
+            if (i + FW < KS) win[i % FW] = k_frag(Kb, i + FW);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // mask, tile maxima, and whether the running max moves (wave-uniform); returns the max the
+    // tile's weights are formed against
+    float alpha = 1.0f;
+    bool moved = false;
+    auto look = [&](int kv0) __attribute__((always_inline)) -> float {
+        if (kv0 + TR > N || (CAUSAL && kv0 + TR - 1 > q0 + wave * 32)) {
 #pragma unroll
-            for (int half = 0; half < KS / KB; ++half) {
-                const int cur = (kb * (KS / KB) + half) & 1, nb = kb * (KS / KB) + half + 1;    // next batch: (key block, half)
-                if (nb < 2 * (KS / KB)) {
-#pragma unroll
-                    for (int j = 0; j < KB; ++j)
-                        ka[cur ^ 1][j] = *reinterpret_cast<const s16x8*>(Kb + k_off_w(32 * (nb / (KS / KB)) + r, 2 * (KB * (nb % (KS / KB)) + j) + h));
-                }
-#pragma unroll
-                for (int j = 0; j < KB; ++j) s[kb] = M::run(ka[cur][j], qf[KB * half + j], s[kb]);
+            for (int i = 0; i < 16; ++i) {
+                const int key = kv0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (key > key_limit) s[i] = -INFINITY;
             }
         }
-
-        // ---- keys past N (last tile) and, under the causal mask, keys after the row (uniform test per wave)
-        if (kv0 + kBKVW > N || (CAUSAL && kv0 + kBKVW - 1 > q0 + wave * 32)) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int key = kv0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (key > key_limit) s[kb][i] = -INFINITY;
-                }
+        float c0 = vmax3(s[0], s[1], s[2]), c1 = vmax3(s[3], s[4], s[5]);
+        c0 = vmax3(c0, s[6], s[7]);
+        c1 = vmax3(c1, s[8], s[9]);
+        c0 = vmax3(c0, s[10], s[11]);
+        c1 = vmax3(c1, s[12], s[13]);
+        const float mt = half_exchange_max(vmax3(c0, c1, vmax2(s[14], s[15]))) * sl2;
+        float m_new = m;
+        moved = __builtin_amdgcn_ballot_w64(mt - m > thr) != 0;   // always in tile 0 (m = -inf)
+        if (moved) {
+            m_new = fmaxf(m, mt);
+            alpha = __builtin_amdgcn_exp2f(m - m_new);
         }
-
-        // ---- online softmax (per query = per lane, two halves cooperate)
-        float c0 = vmax3(s[0][0], s[0][1], s[0][2]), c1 = vmax3(s[1][0], s[1][1], s[1][2]);
-#pragma unroll
-        for (int i = 3; i + 1 < 16; i += 2) {
-            c0 = vmax3(c0, s[0][i], s[0][i + 1]);
-            c1 = vmax3(c1, s[1][i], s[1][i + 1]);
-        }
-        const float tmax = half_exchange_max(vmax3(c0, c1, vmax2(s[0][15], s[1][15])));
-        const float mt = tmax * sl2;
-        if (__builtin_amdgcn_ballot_w64(mt - m > thr) != 0) {   // wave-uniform; always taken in tile 0 (m = -inf)
-            const float m_new = fmaxf(m, mt);
-            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-            m = m_new;
+        return m_new;
+    };
+    float psum = 0.f;
+    auto weight = [&](int i, float m_new) __attribute__((always_inline)) {
+        s[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], sl2, -m_new));
+        psum = i == 0 ? s[i] : psum + s[i];
+    };
+    vec8 pb[2];
+    // behind the tile's last MFMA: O^T and l follow the max, the new weights become the B operand
+    auto settle = [&](float m_new) __attribute__((always_inline)) {
+        if (moved) {
             l *= alpha;
 #pragma unroll
             for (int db = 0; db < DB; ++db)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+            m = m_new;
         }
-        float psum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                s[kb][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], sl2, -m));
-                psum += s[kb][i];
-            }
         l += psum;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pb[st][j] = (T)s[8 * st + j];
+    };
 
-        // ---- O^T += V^T P^T : 4 k-steps of 16 keys x DB row blocks, the V^T fragments of a k-step read
-        // together, one k-step ahead
-        auto v_frag = [&](int step, int db) {
-            const int r0 = 16 * step + 4 * h + tq;             // key row of the first 4-row block
-            const int ch = 4 * db + 2 * tg1 + (tp >> 1);
-            const s16x4 lo = lds_read_tr(Vb + v_off_w(r0, ch) + 8 * (tp & 1));
-            const s16x4 hi = lds_read_tr(Vb + v_off_w(r0 + 8, ch) + 8 * (tp & 1));
-            s16x8 a;
-            a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
-            a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
-            return a;
-        };
-        s16x8 va[2][DB];
+    // tile 0 on its own: nothing to run under yet
+    {
+        s_stream(lds);
+        const float m_new = look(0);
 #pragma unroll
-        for (int db = 0; db < DB; ++db) va[0][db] = v_frag(0, db);
-#pragma unroll
-        for (int step = 0; step < 4; ++step) {
-            if (step + 1 < 4) {
-#pragma unroll
-                for (int db = 0; db < DB; ++db) va[(step + 1) & 1][db] = v_frag(step + 1, db);
-            }
-            vec8 pb;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pb[j] = (T)s[step >> 1][8 * (step & 1) + j];
-#pragma unroll
-            for (int db = 0; db < DB; ++db) o[db] = M::run(va[step & 1][db], pb, o[db]);
+        for (int i = 0; i < 16; ++i) weight(i, m_new);
+        settle(m_new);
+        // (K buffer 0 is fetched into again in the first iteration: everybody has to be through with it)
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // iteration t: K(t+1) in K buffer kc, V(t) in V buffer vc; the fetches of K(t+3) and V(t+2) go
+    // into the buffers K(t) and V(t-1) were read from
+    int kc = 1, kn = 2, kf = 0, vc = 0, vn = 1, vf = 2;
+    for (int t = 0; t < ntiles; ++t) {
+        const char* Kb = lds + kc * TILE_B;
+        const char* Vb = lds + (3 + vc) * TILE_B;
+        const bool more = t + 1 < ntiles;          // uniform
+        float m_new = m;
+        if (more) {
+            s_stream(Kb);
+            m_new = look((t + 1) * TR);
+        } else {
+            moved = false;
+            psum = 0.f;
         }
-
-        // ---- publish the next tile: its buffer was last read before the previous barrier
-        stage_write(buf ^ 1);
-        __syncthreads();
+        {
+            s16x8 win[FW];
+#pragma unroll
+            for (int i = 0; i < FW; ++i) win[i] = v_frag(Vb, i);
+#pragma unroll
+            for (int i = 0; i < NPV; ++i) {
+                const s16x8 a = win[i % FW];
+                o[i % DB] = M::run(a, pb[i / DB], o[i % DB]);
+                if (i + FW < NPV) win[i % FW] = v_frag(Vb, i + FW);
+                // (behind the last tile these work on stale registers and nothing reads the results)
+#pragma unroll
+                for (int e = 0; e < EP; ++e)
+                    if (EP * i + e < 16) weight(EP * i + e, m_new);
+                // The fetches sit behind the tile's last fragment request (hipcc makes a transposing LDS
+                // read wait for every LDS-DMA fetch in flight).  The wait in front confirms this wave's
+                // pieces of K(t+2) and V(t+1), issued an iteration ago.
+                constexpr int S0 = NPV - FW, PPS = (2 * LPT + FW - 1) / FW;
+                if (i == S0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (i >= S0) {
+#pragma unroll
+                    for (int e = 0; e < PPS; ++e) {
+                        const int p = PPS * (i - S0) + e;
+                        if (p < 2 * LPT) fetch_piece(tile_or_end(t + 3), kf, tile_or_end(t + 2), vf, p);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (more) settle(m_new);
+        // K(t+2), V(t+1) complete (all waves' pieces), K(t+1), V(t) released; the bare barrier, not
+        // __syncthreads(), which would first wait for the fetches issued a moment ago
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int kw = kc; kc = kn; kn = kf; kf = kw;
+        const int vw = vc; vc = vn; vn = vf; vf = vw;
     }
 
     // ---- epilogue: O = O^T / l, written as rows; lane (r,h) holds, for its query,
@@ -260,10 +309,11 @@ attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, co
     }
 }
 
-template <typename T>
+template <typename T, int D>
 int launch_wide(const void* q, const void* k, const void* v, void* o, float* lse,
                 int64_t heads, int64_t N, int64_t d, float scale, float thr, bool causal, hipStream_t s) {
-    if (N * d * 2 >= (int64_t)kPastEndW) return fail(MYFA_E_UNSUPPORTED, "attention: N*d=%lld per head too large", (long long)(N * d));
+    // byte offsets inside a head are 32-bit, up to three tiles past its end
+    if ((N + 4 * kBKVW) * d * 2 >= (int64_t)kPastEndW) return fail(MYFA_E_UNSUPPORTED, "attention: N*d=%lld per head too large", (long long)(N * d));
     const int64_t nqblk = cdiv(N, (int64_t)kBQW);
     const int64_t nwg = heads * nqblk;
     if (nwg > 0x7fffffffLL) return fail(MYFA_E_UNSUPPORTED, "attention: too many workgroups (%lld)", (long long)nwg);
@@ -273,8 +323,8 @@ int launch_wide(const void* q, const void* k, const void* v, void* o, float* lse
                       static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
                       static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, thr, (int)d);
     };
-    if (causal) go(attn_fwd_mfma_wide_kernel<T, true>);
-    else go(attn_fwd_mfma_wide_kernel<T, false>);
+    if (causal) go(attn_fwd_mfma_wide_kernel<T, D, true>);
+    else go(attn_fwd_mfma_wide_kernel<T, D, false>);
     return check_launch("attn_fwd_mfma_wide");
 }
 
@@ -283,10 +333,14 @@ int launch_wide(const void* q, const void* k, const void* v, void* o, float* lse
 // dtype: MYFA_F16 or MYFA_BF16; d: a multiple of 8 in 136..256; heads = B*H; scale > 0
 int attn_fwd_mfma_wide(const void* q, const void* k, const void* v, void* o, float* lse,
                        int64_t heads, int64_t N, int64_t d, float scale, float thr, int dtype, bool causal, hipStream_t s) {
-    if (d <= 128 || d > kDW || d % 8 != 0)
+    if (d <= 128 || d > 256 || d % 8 != 0)
         return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16, wide): head dim %lld is not a multiple of 8 in 136..256", (long long)d);
-    if (dtype == MYFA_BF16) return launch_wide<__bf16>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s);
-    if (dtype == MYFA_F16) return launch_wide<_Float16>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s);
+    if (dtype == MYFA_BF16)
+        return d <= 192 ? launch_wide<__bf16, 192>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s)
+                        : launch_wide<__bf16, 256>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s);
+    if (dtype == MYFA_F16)
+        return d <= 192 ? launch_wide<_Float16, 192>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s)
+                        : launch_wide<_Float16, 256>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s);
     return fail(MYFA_E_INVALID, "attention (f16/bf16, wide): dtype tag %d", dtype);
 }
 
