@@ -24,13 +24,14 @@ namespace myfa {
 namespace {
 
 constexpr int kThreadsW = 256;       // 4 waves
-constexpr int kBQW = 128;            // query rows per workgroup
 constexpr int kBKVW = 32;            // keys per tile
+constexpr int kQBW = 2;              // 32-row query blocks per wave
 // A buffer offset no tensor reaches (the launcher keeps a head below it) and that a tile offset
 // added to it cannot wrap: fetches from there read zero without touching memory.
 constexpr int kPastEndW = 0x7FFF0000;
 
-template <typename T, int D, bool CAUSAL>
+// QB: 32-row query blocks per wave (a K or V fragment read from LDS feeds QB MFMAs)
+template <typename T, int D, bool CAUSAL, int QB>
 __global__ void __launch_bounds__(kThreadsW, 1)
 attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* __restrict__ Vg,
                           T* __restrict__ Og, float* __restrict__ LSEg, int N, int nqblk, int nwg,
@@ -39,6 +40,7 @@ attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, co
     using vec8 = typename M::vec8;
     using vec4 = typename M::vec4;
     constexpr int TR = kBKVW;
+    constexpr int RW = 32 * QB, kBQW = 4 * RW;    // query rows per wave, per workgroup
     constexpr int TILE_B = TR * D * 2;            // bytes per K (or V) tile image
     constexpr int KS = D / 16;                    // k-steps of S^T = K Q^T
     constexpr int DB = D / 32;                    // 32-row blocks of O^T
@@ -70,16 +72,18 @@ attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, co
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(Vg + hoff), 0, head_bytes, 0x00020000);
 
     // ---- Q^T fragments: lane (r, h) holds Q[row][16ks + 8h .. +7] for ks = 0..KS-1 (rows past N: zeros)
-    const int qrow = q0 + wave * 32 + r;
-    vec8 qf[KS];
+    const int qrow = q0 + wave * RW + r;          // block qb: + 32 qb
+    vec8 qf[QB][KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int ch = 2 * ks + h;
-        [[maybe_unused]] const int off = ch * 8 < gd ? qrow * gd * 2 + ch * 16 : kPastEndW;
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int ch = 2 * ks + h;
+            [[maybe_unused]] const int off = ch * 8 < gd ? (qrow + 32 * qb) * gd * 2 + ch * 16 : kPastEndW;
 #if defined(__HIP_DEVICE_COMPILE__)
-        qf[ks] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(qrs, off, 0, 0));
+            qf[qb][ks] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(qrs, off, 0, 0));
 #endif
-    }
+        }
 
     // ---- K / V tiles: piece i of wave w is image bytes 1024 (w LPT + i) .. + 1023, lane L at + 16 L,
     // so the image (attn_mfma_common.h) is produced by choosing each lane's SOURCE chunk
@@ -115,32 +119,53 @@ attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, co
         rbase[e] = 16 * D * (r >> 3) + 64 * (r & 7) + 16 * ((2 * e + h) ^ ((r >> 2) & 3));
         tbase[e] = 64 * (4 * h + tq) + 16 * ((2 * tg1 + (tp >> 1)) ^ (2 * e + h)) + 8 * (tp & 1) + 16 * D * e;
     }
-    auto k_frag = [&](const char* Kb, int ks) __attribute__((always_inline)) -> s16x8 {
-        return *reinterpret_cast<const s16x8*>(Kb + rbase[ks & 1] + 512 * (ks >> 1));
+    // The fragment reads are written out as instructions, with their waits (lgkmcnt: LDS answers one
+    // wave's requests in order, so "all but the n youngest" is exact).  Left to the compiler, every LDS
+    // read that follows an LDS-DMA fetch first waits for ALL fetches in flight (it cannot tell the
+    // buffers apart), and a fetch then has one MFMA stream to arrive in instead of a whole iteration.
+    // What orders reads and fetches here: a buffer is fetched into only behind the barrier that
+    // follows its last read, and read only behind the barrier that follows the fetching waves' wait.
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)lds;
+    auto k_frag = [&]([[maybe_unused]] unsigned a0, [[maybe_unused]] unsigned a1, auto ks_) __attribute__((always_inline)) -> s16x8 {
+        constexpr int ks = decltype(ks_)::value;
+        s16x8 a;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a) : "v"((ks & 1) ? a1 : a0), "n"(512 * (ks >> 1)));
+#endif
+        return a;
     };
-    auto v_frag = [&](const char* Vb, int i) __attribute__((always_inline)) -> s16x8 {
-        const int st = i / DB, db = i % DB;       // 16 keys x 32 columns
-        const int imm = 16 * D * 2 * st + 512 * db;
-        const s16x4 lo = lds_read_tr(Vb + tbase[0] + imm);
-        const s16x4 hi = lds_read_tr(Vb + tbase[1] + imm);
+    auto v_frag = [&]([[maybe_unused]] unsigned a0, [[maybe_unused]] unsigned a1, auto i_) __attribute__((always_inline)) -> s16x8 {
+        constexpr int i = decltype(i_)::value, st = i / DB, db = i % DB;       // 16 keys x 32 columns
+        s16x4 lo, hi;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "n"(16 * D * 2 * st + 512 * db));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "n"(16 * D * 2 * st + 512 * db));
+#endif
         s16x8 a;
         a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
         a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
         return a;
     };
+    auto lgkm_wait = [&](auto n_) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(decltype(n_)::value));
+    };
 
-    f32x16 o[DB];
+    f32x16 o[QB][DB];
+    float m[QB], l[QB];    // running (deferred) row max of scale*log2(e)*S; this lane half's share of the row sum
 #pragma unroll
-    for (int db = 0; db < DB; ++db)
+    for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
-    float m = -INFINITY;   // running (deferred) row max of scale*log2(e)*S
-    float l = 0.f;         // this lane half's share of the running row sum
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[qb][db][i] = 0.f;
+        m[qb] = -INFINITY;
+        l[qb] = 0.f;
+    }
 
     const int T_all = (N + TR - 1) / TR;
     const int ntiles = CAUSAL ? min(T_all, (q0 + kBQW) / TR) : T_all;
     // the last key a row may see: tile 0 always holds key 0, which every row sees
-    const int key_limit = CAUSAL ? min(N - 1, qrow) : N - 1;
+    auto key_limit = [&](int qb) __attribute__((always_inline)) { return CAUSAL ? min(N - 1, qrow + 32 * qb) : N - 1; };
     auto tile_or_end = [&](int t) __attribute__((always_inline)) { return t < ntiles ? t : T_all; };   // past the end: zeros
 
     // prologue: K(0), V(0), K(1) -- and V(1), K(2) in flight behind them
@@ -155,80 +180,123 @@ attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, co
 
     constexpr int FW = 4;                          // LDS fragments requested ahead of the MFMA stream
     constexpr int NPV = 2 * DB;                    // MFMAs of O^T += V^T P^T per tile
-    constexpr int EP = (16 + NPV - 1) / NPV;       // weights formed per MFMA of that stream
+    constexpr int EP = (16 * QB + NPV - 1) / NPV;  // weights formed per step of that stream
 
-    f32x16 s;
+    f32x16 s[QB];
+    // S^T and O^T come from MFMAs the compiler does not see as such (Mma::acc_v, acc_a): whoever reads
+    // them with a vector instruction first waits out the last one's result latency (8 passes of 4 cycles
+    // and change)
+    auto mfma_drain = [&]() __attribute__((always_inline)) {
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    };
     // S^T of one tile: key (i & 3) + 8 (i >> 2) + 4 h of the tile in register i
-    auto s_stream = [&](const char* Kb) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+    auto s_stream = [&](int kbuf) __attribute__((always_inline)) {
+        const unsigned a0 = lds0 + kbuf * TILE_B + rbase[0], a1 = lds0 + kbuf * TILE_B + rbase[1];
         s16x8 win[FW];
-#pragma unroll
-        for (int i = 0; i < FW; ++i) win[i] = k_frag(Kb, i);
-#pragma unroll
-        for (int i = 0; i < KS; ++i) {
+        static_for<FW>([&](auto ic) __attribute__((always_inline)) { win[decltype(ic)::value] = k_frag(a0, a1, ic); });
+        static_for<KS>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            lgkm_wait(IC<(KS - 1 - i < FW - 1 ? KS - 1 - i : FW - 1)>{});
             const s16x8 a = win[i % FW];
-            s = M::run(a, qf[i], s);
-            if (i + FW < KS) win[i % FW] = k_frag(Kb, i + FW);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                // pinned to vector registers (the accumulator file belongs to O^T)
+                if constexpr (i == 0) M::first_v(a, qf[qb][0], s[qb]);
+                else M::acc_v(a, qf[qb][i], s[qb]);
+            }
+            if constexpr (i + FW < KS) win[i % FW] = k_frag(a0, a1, IC<i + FW>{});
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
+        mfma_drain();
     };
     // mask, tile maxima, and whether the running max moves (wave-uniform); returns the max the
     // tile's weights are formed against
-    float alpha = 1.0f;
+    float m_new[QB];
     bool moved = false;
-    auto look = [&](int kv0) __attribute__((always_inline)) -> float {
-        if (kv0 + TR > N || (CAUSAL && kv0 + TR - 1 > q0 + wave * 32)) {
+    auto look = [&](int kv0) __attribute__((always_inline)) {
+        if (kv0 + TR > N || (CAUSAL && kv0 + TR - 1 > q0 + wave * RW)) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int key = kv0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (key > key_limit) s[i] = -INFINITY;
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kv0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key > key_limit(qb)) s[qb][i] = -INFINITY;
+                }
+        }
+        float mt[QB];
+        bool grew = false;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float c0 = vmax3(s[qb][0], s[qb][1], s[qb][2]), c1 = vmax3(s[qb][3], s[qb][4], s[qb][5]);
+            c0 = vmax3(c0, s[qb][6], s[qb][7]);
+            c1 = vmax3(c1, s[qb][8], s[qb][9]);
+            c0 = vmax3(c0, s[qb][10], s[qb][11]);
+            c1 = vmax3(c1, s[qb][12], s[qb][13]);
+            mt[qb] = half_exchange_max(vmax3(c0, c1, vmax2(s[qb][14], s[qb][15]))) * sl2;
+            grew = grew || mt[qb] - m[qb] > thr;
+        }
+        moved = __builtin_amdgcn_ballot_w64(grew) != 0;   // always in tile 0 (m = -inf)
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            m_new[qb] = m[qb];
+            if (moved) m_new[qb] = fmaxf(m[qb], mt[qb]);
+        }
+    };
+    float psum[QB];
+    // weight e of the wave's 16 QB: block e % QB, register e / QB
+    auto weight = [&](int e) __attribute__((always_inline)) {
+        const int qb = e % QB, i = e / QB;
+        s[qb][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][i], sl2, -m_new[qb]));
+        psum[qb] = i == 0 ? s[qb][i] : psum[qb] + s[qb][i];
+    };
+    vec8 pb[QB][2];
+    // behind the tile's last MFMA: O^T and l follow the max, the new weights become the B operand
+    auto settle = [&](auto first_) __attribute__((always_inline)) {
+        if constexpr (decltype(first_)::value != 0) {
+            // tile 0: O^T and l are still zero, the max simply starts
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) m[qb] = m_new[qb];
+        } else if (moved) {
+            mfma_drain();
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const float alpha = __builtin_amdgcn_exp2f(m[qb] - m_new[qb]);
+                l[qb] *= alpha;
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        // through one vector register at a time: O^T stays in accumulator registers
+                        // (left to the compiler the whole tile is copied out, scaled and copied back,
+                        // and at 64 rows x 256 columns per wave that no longer fits)
+                        float x = o[qb][db][i];
+#if defined(__HIP_DEVICE_COMPILE__)
+                        float tmp;
+                        asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\tv_accvgpr_write_b32 %0, %1"
+                                     : "+a"(x), "=&v"(tmp) : "v"(alpha));
+#endif
+                        o[qb][db][i] = x;
+                    }
+                m[qb] = m_new[qb];
             }
         }
-        float c0 = vmax3(s[0], s[1], s[2]), c1 = vmax3(s[3], s[4], s[5]);
-        c0 = vmax3(c0, s[6], s[7]);
-        c1 = vmax3(c1, s[8], s[9]);
-        c0 = vmax3(c0, s[10], s[11]);
-        c1 = vmax3(c1, s[12], s[13]);
-        const float mt = half_exchange_max(vmax3(c0, c1, vmax2(s[14], s[15]))) * sl2;
-        float m_new = m;
-        moved = __builtin_amdgcn_ballot_w64(mt - m > thr) != 0;   // always in tile 0 (m = -inf)
-        if (moved) {
-            m_new = fmaxf(m, mt);
-            alpha = __builtin_amdgcn_exp2f(m - m_new);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            l[qb] += psum[qb];
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[qb][st][j] = (T)s[qb][8 * st + j];
         }
-        return m_new;
-    };
-    float psum = 0.f;
-    auto weight = [&](int i, float m_new) __attribute__((always_inline)) {
-        s[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], sl2, -m_new));
-        psum = i == 0 ? s[i] : psum + s[i];
-    };
-    vec8 pb[2];
-    // behind the tile's last MFMA: O^T and l follow the max, the new weights become the B operand
-    auto settle = [&](float m_new) __attribute__((always_inline)) {
-        if (moved) {
-            l *= alpha;
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
-            m = m_new;
-        }
-        l += psum;
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pb[st][j] = (T)s[8 * st + j];
     };
 
     // tile 0 on its own: nothing to run under yet
     {
-        s_stream(lds);
-        const float m_new = look(0);
+        s_stream(0);
+        look(0);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) weight(i, m_new);
-        settle(m_new);
+        for (int e = 0; e < 16 * QB; ++e) weight(e);
+        settle(IC<1>{});
         // (K buffer 0 is fetched into again in the first iteration: everybody has to be through with it)
         __builtin_amdgcn_s_barrier();
     }
@@ -237,36 +305,31 @@ attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, co
     // into the buffers K(t) and V(t-1) were read from
     int kc = 1, kn = 2, kf = 0, vc = 0, vn = 1, vf = 2;
     for (int t = 0; t < ntiles; ++t) {
-        const char* Kb = lds + kc * TILE_B;
-        const char* Vb = lds + (3 + vc) * TILE_B;
         const bool more = t + 1 < ntiles;          // uniform
-        float m_new = m;
         if (more) {
-            s_stream(Kb);
-            m_new = look((t + 1) * TR);
-        } else {
-            moved = false;
-            psum = 0.f;
+            s_stream(kc);
+            look((t + 1) * TR);
         }
         {
+            const unsigned a0 = lds0 + (3 + vc) * TILE_B + tbase[0], a1 = lds0 + (3 + vc) * TILE_B + tbase[1];
             s16x8 win[FW];
-#pragma unroll
-            for (int i = 0; i < FW; ++i) win[i] = v_frag(Vb, i);
-#pragma unroll
-            for (int i = 0; i < NPV; ++i) {
+            static_for<FW>([&](auto ic) __attribute__((always_inline)) { win[decltype(ic)::value] = v_frag(a0, a1, ic); });
+            static_for<NPV>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                lgkm_wait(IC<2 * (NPV - 1 - i < FW - 1 ? NPV - 1 - i : FW - 1)>{});
                 const s16x8 a = win[i % FW];
-                o[i % DB] = M::run(a, pb[i / DB], o[i % DB]);
-                if (i + FW < NPV) win[i % FW] = v_frag(Vb, i + FW);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) M::acc_a(a, pb[qb][i / DB], o[qb][i % DB]);
+                if constexpr (i + FW < NPV) win[i % FW] = v_frag(a0, a1, IC<i + FW>{});
                 // (behind the last tile these work on stale registers and nothing reads the results)
 #pragma unroll
                 for (int e = 0; e < EP; ++e)
-                    if (EP * i + e < 16) weight(EP * i + e, m_new);
-                // The fetches sit behind the tile's last fragment request (hipcc makes a transposing LDS
-                // read wait for every LDS-DMA fetch in flight).  The wait in front confirms this wave's
-                // pieces of K(t+2) and V(t+1), issued an iteration ago.
+                    if (EP * i + e < 16 * QB) weight(EP * i + e);
+                // The fetches of K(t+3), V(t+2) are spread over the stream's last steps; the wait in front
+                // confirms this wave's pieces of K(t+2) and V(t+1), issued an iteration ago.
                 constexpr int S0 = NPV - FW, PPS = (2 * LPT + FW - 1) / FW;
-                if (i == S0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (i >= S0) {
+                if constexpr (i == S0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if constexpr (i >= S0) {
 #pragma unroll
                     for (int e = 0; e < PPS; ++e) {
                         const int p = PPS * (i - S0) + e;
@@ -274,9 +337,9 @@ attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, co
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            });
         }
-        if (more) settle(m_new);
+        if (more) settle(IC<0>{});
         // K(t+2), V(t+1) complete (all waves' pieces), K(t+1), V(t) released; the bare barrier, not
         // __syncthreads(), which would first wait for the fetches issued a moment ago
         asm volatile("" ::: "memory");
@@ -288,33 +351,38 @@ attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, co
 
     // ---- epilogue: O = O^T / l, written as rows; lane (r,h) holds, for its query,
     // d = 32db + 8g + 4h + (0..3) in registers 4g..4g+3 of block db
-    const float ltot = half_exchange_sum(l);
-    const float inv = 1.0f / ltot;
-    if (qrow < N) {
-        T* orow = Og + hoff + (size_t)qrow * gd;
+    mfma_drain();
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
+    for (int qb = 0; qb < QB; ++qb) {
+        const float ltot = half_exchange_sum(l[qb]);
+        const float inv = 1.0f / ltot;
+        const int row = qrow + 32 * qb;
+        if (row < N) {
+            T* orow = Og + hoff + (size_t)row * gd;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = 32 * db + 8 * g + 4 * h;
-                if (col < gd) {               // (gd is a multiple of 8: the four columns are in or out together)
-                    vec4 w;
+            for (int db = 0; db < DB; ++db)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) w[j] = (T)(o[db][4 * g + j] * inv);
-                    *reinterpret_cast<vec4*>(orow + col) = w;
+                for (int g = 0; g < 4; ++g) {
+                    const int col = 32 * db + 8 * g + 4 * h;
+                    if (col < gd) {               // (gd is a multiple of 8: the four columns are in or out together)
+                        vec4 w;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) w[j] = (T)(o[qb][db][4 * g + j] * inv);
+                        *reinterpret_cast<vec4*>(orow + col) = w;
+                    }
                 }
-            }
-        if (LSEg != nullptr && h == 0)
-            LSEg[(size_t)head * N + qrow] = (m + __builtin_amdgcn_logf(ltot)) * 0.6931471805599453f;
+            if (LSEg != nullptr && h == 0)
+                LSEg[(size_t)head * N + row] = (m[qb] + __builtin_amdgcn_logf(ltot)) * 0.6931471805599453f;
+        }
     }
 }
 
-template <typename T, int D>
+template <typename T, int D, int QB>
 int launch_wide(const void* q, const void* k, const void* v, void* o, float* lse,
                 int64_t heads, int64_t N, int64_t d, float scale, float thr, bool causal, hipStream_t s) {
     // byte offsets inside a head are 32-bit, up to three tiles past its end
     if ((N + 4 * kBKVW) * d * 2 >= (int64_t)kPastEndW) return fail(MYFA_E_UNSUPPORTED, "attention: N*d=%lld per head too large", (long long)(N * d));
-    const int64_t nqblk = cdiv(N, (int64_t)kBQW);
+    const int64_t nqblk = cdiv(N, (int64_t)(128 * QB));
     const int64_t nwg = heads * nqblk;
     if (nwg > 0x7fffffffLL) return fail(MYFA_E_UNSUPPORTED, "attention: too many workgroups (%lld)", (long long)nwg);
     const float sl2 = scale * 1.4426950408889634f;
@@ -323,8 +391,8 @@ int launch_wide(const void* q, const void* k, const void* v, void* o, float* lse
                       static_cast<const T*>(q), static_cast<const T*>(k), static_cast<const T*>(v),
                       static_cast<T*>(o), lse, (int)N, (int)nqblk, (int)nwg, sl2, thr, (int)d);
     };
-    if (causal) go(attn_fwd_mfma_wide_kernel<T, D, true>);
-    else go(attn_fwd_mfma_wide_kernel<T, D, false>);
+    if (causal) go(attn_fwd_mfma_wide_kernel<T, D, true, QB>);
+    else go(attn_fwd_mfma_wide_kernel<T, D, false, QB>);
     return check_launch("attn_fwd_mfma_wide");
 }
 
@@ -336,11 +404,11 @@ int attn_fwd_mfma_wide(const void* q, const void* k, const void* v, void* o, flo
     if (d <= 128 || d > 256 || d % 8 != 0)
         return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16, wide): head dim %lld is not a multiple of 8 in 136..256", (long long)d);
     if (dtype == MYFA_BF16)
-        return d <= 192 ? launch_wide<__bf16, 192>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s)
-                        : launch_wide<__bf16, 256>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s);
+        return d <= 192 ? launch_wide<__bf16, 192, kQBW>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s)
+                        : launch_wide<__bf16, 256, kQBW>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s);
     if (dtype == MYFA_F16)
-        return d <= 192 ? launch_wide<_Float16, 192>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s)
-                        : launch_wide<_Float16, 256>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s);
+        return d <= 192 ? launch_wide<_Float16, 192, kQBW>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s)
+                        : launch_wide<_Float16, 256, kQBW>(q, k, v, o, lse, heads, N, d, scale, thr, causal, s);
     return fail(MYFA_E_INVALID, "attention (f16/bf16, wide): dtype tag %d", dtype);
 }
 

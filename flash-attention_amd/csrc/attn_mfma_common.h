@@ -28,6 +28,8 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 //          these, so the caller keeps the result-latency rule: no vector instruction may read or
 //          write c until two further MFMAs have been issued behind the last one that wrote it
 //          (8 passes = 32 cycles each; the rule asks for 11 issue slots of 4 cycles).
+// acc_a(): the same with the accumulator pinned to ACCUMULATOR registers, for a tile that nothing but
+//          MFMAs touches in the loop (the same rule holds for whatever reads it afterwards).
 template <typename T> struct Mma;
 template <> struct Mma<__bf16> {
     using vec8 = bf16x8;
@@ -45,6 +47,11 @@ template <> struct Mma<__bf16> {
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
 #endif
     }
+    static __device__ __forceinline__ void acc_a([[maybe_unused]] s16x8 a, [[maybe_unused]] vec8 b, [[maybe_unused]] f32x16& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+#endif
+    }
 };
 template <> struct Mma<_Float16> {
     using vec8 = f16x8;
@@ -60,6 +67,11 @@ template <> struct Mma<_Float16> {
     static __device__ __forceinline__ void first_v([[maybe_unused]] s16x8 a, [[maybe_unused]] vec8 b, [[maybe_unused]] f32x16& c) {
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+#endif
+    }
+    static __device__ __forceinline__ void acc_a([[maybe_unused]] s16x8 a, [[maybe_unused]] vec8 b, [[maybe_unused]] f32x16& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 #endif
     }
 };
