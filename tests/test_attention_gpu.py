@@ -50,9 +50,15 @@ def test_my_attention_vs_golden(mfa, n, d):
     assert out.shape == (n, d) and out.dtype == torch.float32
     o = out.cpu().numpy()
     exact = ref_cpu.attention_naive(g["q"], g["k"], g["v"])
-    assert _maxdiff(o, exact) <= F32_ATOL
+    dist = {"float64 oracle": _maxdiff(o, exact)}
+    dist.update({key: _maxdiff(o, g[key]) for key in ("out_ref_naive", "out_ref_flash", "out_sdpa")})
+    # the measured distances, for the record (pytest -s / -rA shows them): to the exact result, and to the
+    # reference's own float32 outputs, which are themselves 1.1-1.4e-5 from exact at n = 1024
+    print(f"my_attention {n}x{d}: " + ", ".join(f"|out - {k}| = {v:.3e}" for k, v in dist.items())
+          + f"; |out_ref_naive - float64 oracle| = {_maxdiff(g['out_ref_naive'], exact):.3e}")
+    assert dist["float64 oracle"] <= F32_ATOL
     for key in ("out_ref_naive", "out_ref_flash", "out_sdpa"):
-        assert _maxdiff(o, g[key]) < REF_ATOL
+        assert dist[key] < REF_ATOL
 
 
 @pytest.mark.parametrize("n,d", [(1, 7), (17, 1), (65, 33), (130, 64), (300, 100), (64, 128), (200, 130), (50, 257)])

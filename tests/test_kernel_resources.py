@@ -1,5 +1,7 @@
-"""Register budgets of the resident-workgroup attention forward, checked on the gfx950 code hipcc
-generates (CPU-only: hipcc cross-compiles).
+"""Register budgets of the attention kernels whose speed depends on them, checked on the gfx950 code
+hipcc generates (CPU-only: hipcc cross-compiles).
+
+The resident-workgroup forward (head dims up to 128):
 
 The kernel's speed rests on two properties of its register allocation that a source edit can lose
 without any test of results noticing: no scalar register is spilled in any build (scalar spills are
@@ -7,6 +9,13 @@ v_readlane / v_writelane traffic inside the tile loop: the causal builds lost 9 
 mask was written as VCC compare/select pairs), and the builds the dispatch uses by itself -- head
 dim 128, and head dim 64 with one workgroup per CU -- spill no vector register to scratch memory
 (at most a handful outside the loops in the causal build that carries both softmax forms).
+
+The one-wave-per-SIMD kernels for head dims above 128 (forward and backward): a spilled vector
+register inside their tile loop costs far more than its two instructions, because scratch traffic
+shares the counter (vmcnt) on which the LDS-DMA fetches of the coming tiles are waited for -- every
+reload then waits for the fetches issued a moment ago.  The 256-column forward uses all 512
+registers of a lane; the few values it spills live outside the loop (checked on the code: no
+scratch instruction between the loop's barriers).
 """
 import importlib.util
 import os
@@ -83,3 +92,38 @@ def test_resident_workgroup_forward_register_budgets():
             assert r["vgpr_count"] <= 128, (name, r)                          # two workgroups per CU
             assert 2 * r["group_segment_fixed_size"] <= 160 * 1024, (name, r)
     assert seen >= 2 * (5 + 10), f"only {seen} builds of the kernel found"
+
+
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="needs hipcc")
+def test_wide_head_kernels_register_budgets():
+    haz = _load("check_mfma_hazards", os.path.join(ROOT, "tools", "check_mfma_hazards.py"))
+    build = _load("myfa_build", os.path.join(ROOT, "flash-attention_amd", "build.py"))
+    seen = 0
+    for src, kern in (("attn_fwd_mfma256.hip", "attn_fwd_mfma_wide_kernel"), ("attn_bwd_wide.hip", "attn_bwd_d")):
+        asm = haz.compile_to_asm(os.path.join(build.CSRC, src), build.PER_SOURCE_FLAGS.get(src, []))
+        res = {k: v for k, v in kernel_resources(asm).items() if kern in k and "vgpr_count" in v}
+        for name, r in res.items():
+            seen += 1
+            assert r["sgpr_spill_count"] == 0, (name, r)
+            assert r["vgpr_count"] <= 512 and r["group_segment_fixed_size"] <= 160 * 1024, (name, r)
+            wide256_fwd = "attn_fwd_mfma_wide_kernel" in name and "Li256E" in name
+            assert r["vgpr_spill_count"] <= (4 if wide256_fwd else 0), (name, r)
+        if src == "attn_fwd_mfma256.hip":
+            # the tile loop of every build is free of scratch traffic: between the first bare s_barrier
+            # inside a loop and the loop's back edge there is no scratch instruction
+            for body in re.split(r"\n\s+s_endpgm", asm):
+                m = re.search(r"^(_ZN4myfa\S*attn_fwd_mfma_wide_kernel\S*):", body, re.M)
+                if not m:
+                    continue
+                lines = body[m.end():].split("\n")
+                labels = {ln.split(":")[0]: i for i, ln in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:", ln)}
+                loops = []
+                for i, ln in enumerate(lines):
+                    b = re.match(r"^\s+s_c?branch\w*\s+(\.LBB\d+_\d+)", ln)
+                    if b and labels.get(b.group(1), i + 1) < i:                  # a backward branch
+                        loops.append((labels[b.group(1)], i))
+                mfma_loops = [(a, z) for a, z in loops if sum("v_mfma" in ln for ln in lines[a:z]) >= 16]
+                assert mfma_loops, m.group(1)
+                for a, z in mfma_loops:
+                    assert not any("scratch_" in ln for ln in lines[a:z]), (m.group(1), a, z)
+    assert seen >= 8 + 24, f"only {seen} builds found"
