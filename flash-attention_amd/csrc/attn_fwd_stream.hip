@@ -59,7 +59,13 @@ constexpr int kPastEndS = 0x7FFF0000;
 // The launcher uses it only where logits are small (the regime it picks SPEC in): rounding
 // Q * scale * log2(e) to bfloat16 moves a logit by ~2^-9 of its size, 0.005 base-2 units at most there.
 // WIDE (D = 64 only): one workgroup per CU with 256 registers per lane instead of two with 128.
-template <typename T, int D, bool CAUSAL, bool SPEC, bool PRE = false, bool WIDE = false>
+// LM (with SPEC, without PRE and the mask): the row sums come out of the matrix cores -- one more MFMA
+// per 32 keys and query block, a fragment of ones against the weights' B operand -- so they are sums
+// of the ROUNDED weights: numerator and denominator of O carry the same rounding, which is what
+// lets the speculative softmax run on large (unscaled) logits, where a row is mostly one dominant
+// key and its weight's rounding would otherwise stand against an exact sum.  The go-back test looks
+// at the largest weight instead of the row sum.
+template <typename T, int D, bool CAUSAL, bool SPEC, bool PRE = false, bool WIDE = false, bool LM = false>
 __global__ void __launch_bounds__(kThreadsS, D == 64 && !WIDE ? 4 : 2)
 attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const T* __restrict__ Vg,
                        T* __restrict__ Og, float* __restrict__ LSEg, int N, int nqblk, int hp, int nunits,
@@ -181,8 +187,19 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
     for (int p = 0; p < 2; ++p)
         vbase[p] = SUB_B * (g >> 1) + 64 * (4 * (g & 1) + tq) + 16 * ((2 * p + (tp >> 1)) ^ (2 * (g & 1))) + 8 * (tp & 1);
 
+    static_assert(!LM || (SPEC && !PRE && !CAUSAL), "LM goes with the unmasked speculative softmax on unscaled Q");
     f32x4 o[DB][2];
     float m[2], l[2];
+    [[maybe_unused]] f32x4 lacc[2];              // LM: the row sums, every register of a tuple the lane's query's
+    [[maybe_unused]] s16x8 ones;                 // LM: an A fragment of ones
+    if constexpr (LM) {
+        vec8 one8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) one8[j] = (T)1.0f;
+        u32x4 w = __builtin_bit_cast(u32x4, one8);
+        asm volatile("" : "+v"(w));              // (kept in registers: an MFMA operand cannot be a constant)
+        ones = __builtin_bit_cast(s16x8, w);
+    }
     auto clear_state = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int db = 0; db < DB; ++db)
@@ -192,6 +209,12 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
                 for (int r = 0; r < 4; ++r) o[db][qb][r] = 0.f;
         m[0] = m[1] = -INFINITY;
         l[0] = l[1] = 0.f;
+        if constexpr (LM) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lacc[qb][r] = 0.f;
+        }
     };
     clear_state();
     f32x4 s[4][2];
@@ -299,6 +322,12 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
                 const int st = (i - NQ) / DB, db = (i - NQ) % DB;
                 o[db][0] = M::run(a, pb[st][0], o[db][0]);
                 o[db][1] = M::run(a, pb[st][1], o[db][1]);
+                if constexpr (LM) {
+                    if (db == DB / 2) {
+                        lacc[0] = M::run(ones, pb[st][0], lacc[0]);
+                        lacc[1] = M::run(ones, pb[st][1], lacc[1]);
+                    }
+                }
             }
             if (i + FW < LAST) win[(i - FIRST) % FW] = frag(ck_addr, cv_addr, i + FW);
             after(i);
@@ -366,6 +395,10 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
                 const float alpha = __builtin_amdgcn_exp2f(m[qb] - m_new);
                 m[qb] = m_new;
                 l[qb] *= alpha;
+                if constexpr (LM) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) lacc[qb][r] *= alpha;
+                }
 #pragma unroll
                 for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -387,8 +420,10 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         p[kb][qb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][qb][r], sl2, -m[qb]));
-                        if (kb == 0 && r == 0) psum[qb] = p[kb][qb][r];
-                        else psum[qb] += p[kb][qb][r];
+                        if constexpr (!LM) {
+                            if (kb == 0 && r == 0) psum[qb] = p[kb][qb][r];
+                            else psum[qb] += p[kb][qb][r];
+                        }
                     }
             }
         };
@@ -434,6 +469,19 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
             }
         } else if constexpr (SPECULATE) {
             weights();
+            if constexpr (LM) {
+                // the lane's largest weight per query stands in for its row sum (which the matrix cores form)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    float a = vmax3(p[0][qb][0], p[0][qb][1], p[0][qb][2]);
+                    float b = vmax3(p[2][qb][0], p[2][qb][1], p[2][qb][2]);
+                    a = vmax3(a, p[0][qb][3], p[1][qb][0]);
+                    b = vmax3(b, p[2][qb][3], p[3][qb][0]);
+                    a = vmax3(a, p[1][qb][1], p[1][qb][2]);
+                    b = vmax3(b, p[3][qb][1], p[3][qb][2]);
+                    psum[qb] = vmax3(a, b, vmax2(p[1][qb][3], p[3][qb][3]));
+                }
+            }
             // negated comparisons: a NaN or an infinite sum goes back too
             if (__builtin_amdgcn_ballot_w64(!(psum[0] <= lim) || !(psum[1] <= lim)) != 0) {   // wave-uniform
                 float tmax[2];
@@ -462,8 +510,10 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
             }
             weights();
         }
-        l[0] += psum[0];
-        l[1] += psum[1];
+        if constexpr (!LM) {
+            l[0] += psum[0];
+            l[1] += psum[1];
+        }
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -487,7 +537,9 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
     // own LDS region 16 rows at a time and stored as whole rows (16 bytes per lane, each row
     // contiguous); then O, m, l are cleared for the next item.
     auto store_item = [&]() __attribute__((always_inline)) {
-        const Pair ltot = four_row_reduce(l[0], l[1], SumOp{});
+        Pair ltot;
+        if constexpr (LM) ltot = Pair{lacc[0][0], lacc[1][0]};        // complete: the MFMA sums over all keys
+        else ltot = four_row_reduce(l[0], l[1], SumOp{});
         const float inv[2] = {1.0f / ltot.a, 1.0f / ltot.b};
         char* obuf = lds + RING_B + wave_u * PARK_B;
         const size_t hoff = (size_t)cur.head * head_elems;
@@ -709,7 +761,7 @@ int cu_count_current() {
 
 template <typename T, int D>
 int launch_stream(const void* q, const void* k, const void* v, void* o, float* lse,
-                  int64_t heads, int64_t N, int64_t d, float scale, float thr, bool spec, bool pre, bool causal, int wgs, bool wide, hipStream_t s) {
+                  int64_t heads, int64_t N, int64_t d, float scale, float thr, bool spec, bool pre, bool lm, bool causal, int wgs, bool wide, hipStream_t s) {
     if (N * d * 2 >= (int64_t)kPastEndS) return fail(MYFA_E_UNSUPPORTED, "attention: N*d=%lld per head too large", (long long)(N * d));
     const int64_t nqblk = cdiv(N, kBQS);
     // units of work: query blocks, or under the causal mask pairs of mirrored query blocks of a head
@@ -742,6 +794,12 @@ int launch_stream(const void* q, const void* k, const void* v, void* o, float* l
             return check_launch("attn_fwd_stream");
         }
     }
+    if constexpr (D == 128) {
+        if (!causal && spec && !pre && lm) {
+            go(attn_fwd_stream_kernel<T, D, false, true, false, false, true>);
+            return check_launch("attn_fwd_stream");
+        }
+    }
     if (causal && spec && pre) go(attn_fwd_stream_kernel<T, D, true, true, true>);
     else if (causal) go(attn_fwd_stream_kernel<T, D, true, false>);
     else if (spec && pre) go(attn_fwd_stream_kernel<T, D, false, true, true>);
@@ -764,7 +822,20 @@ int attn_fwd_stream(const void* q, const void* k, const void* v, void* o, float*
     // beats the one-block-per-workgroup kernel by 8-14 % at B4 H32 N4096 d64 and 10 % at B8 H16 N1024
     // d64, and without the mask loses 6-9 % to it -- the dispatch sends only causal launches here.)
     const bool wide = d <= 64 && occ != 2;
-    const bool sp = spec < 0 ? scale * 1.4426950408889634f * sqrtf((float)d) <= 4.0f : spec != 0;
+    // spec: 0 = the max of every tile and a vote; 1 = speculative; 2 = speculative with the row sums
+    // formed by the matrix cores (head dims above 64, no mask); < 0 = the library's choice: 1 where
+    // the logits of unit-variance inputs would spread by at most 4 base-2 units; beyond that 2 for
+    // bfloat16 (whose weights have the exponent range to sit 2^60 above a stale max: on such logits
+    // the max of a row stops moving by that much after its first tiles; measured +12 % over the
+    // vote at scale = 1, d = 128) and 0 for float16, whose weights overflow at 2^16.
+    const bool small_logits = scale * 1.4426950408889634f * sqrtf((float)d) <= 4.0f;
+    // (Not by itself when the row statistic is asked for: a sum of weights rounded to 8 bits moves
+    // log-sum-exp by up to 2^-9, and a backward recomputes P against exactly that statistic.)
+    // (2 where that build does not exist -- head dims up to 64, the causal mask -- is the library's choice.)
+    const bool lm_ok = d > 64 && !causal;
+    const bool choose = spec < 0 || (spec == 2 && !lm_ok);
+    const bool lm = lm_ok && (spec == 2 || (choose && !small_logits && dtype == MYFA_BF16 && lse == nullptr));
+    const bool sp = choose ? small_logits || lm : spec != 0;
     // pre: < 0 = the library's choice: wherever the speculative build runs and no row statistic is
     // asked for (inference).  The rounding of Q * scale * log2(e) moves a logit by ~2^-9 of its size --
     // the order of the rounding the 16-bit inputs already carry, and far inside the output's bound --
@@ -773,17 +844,17 @@ int attn_fwd_stream(const void* q, const void* k, const void* v, void* o, float*
     // Else forced on / off (tuning flavour).
     // (Head dims up to 64 with two workgroups per CU: never by itself -- that build already spills
     // registers and loses a third with it.)
-    const bool pr = sp && (pre < 0 ? lse == nullptr && (d > 64 || wide) : pre != 0);
-    if (thr < 0.f) thr = !sp || (causal && !pr) ? 8.f : dtype == MYFA_BF16 ? 30.f : 12.f;
+    const bool pr = sp && !lm && (pre < 0 ? lse == nullptr && (d > 64 || wide) : pre != 0);
+    if (thr < 0.f) thr = !sp || (causal && !pr) ? 8.f : dtype != MYFA_BF16 ? 12.f : lm ? 60.f : 30.f;
     if (dtype == MYFA_F16 && thr > 15.f) thr = 15.f;
     if (thr > 60.f) thr = 60.f;
     // head dims that are multiples of 8 run on the next build up, the missing columns read as zeros
     if (d >= 8 && d <= 128 && d % 8 == 0) {
         const bool big = d > 64;
-        if (dtype == MYFA_BF16) return big ? launch_stream<__bf16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, causal, wgs, wide, s)
-                                           : launch_stream<__bf16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, causal, wgs, wide, s);
-        if (dtype == MYFA_F16)  return big ? launch_stream<_Float16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, causal, wgs, wide, s)
-                                           : launch_stream<_Float16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, causal, wgs, wide, s);
+        if (dtype == MYFA_BF16) return big ? launch_stream<__bf16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, lm, causal, wgs, wide, s)
+                                           : launch_stream<__bf16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, lm, causal, wgs, wide, s);
+        if (dtype == MYFA_F16)  return big ? launch_stream<_Float16, 128>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, lm, causal, wgs, wide, s)
+                                           : launch_stream<_Float16, 64>(q, k, v, o, lse, heads, N, d, scale, thr, sp, pr, lm, causal, wgs, wide, s);
     }
     return fail(MYFA_E_UNSUPPORTED, "attention (f16/bf16): head dim %lld is not a multiple of 8 in 8..128", (long long)d);
 }

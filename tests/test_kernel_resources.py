@@ -75,16 +75,16 @@ def test_resident_workgroup_forward_register_budgets():
     src = "attn_fwd_stream.hip"
     asm = haz.compile_to_asm(os.path.join(build.CSRC, src), build.PER_SOURCE_FLAGS.get(src, []))
     res = {k: v for k, v in kernel_resources(asm).items() if "attn_fwd_stream_kernel" in k and "vgpr_count" in v}
-    # template arguments in the mangled name: <T, D, CAUSAL, SPEC, PRE, WIDE>
+    # template arguments in the mangled name: <T, D, CAUSAL, SPEC, PRE, WIDE, LM>
     seen = 0
     for name, r in res.items():
-        m = re.search(r"attn_fwd_stream_kernelI(\w+?)Li(\d+)ELb(\d)ELb(\d)ELb(\d)ELb(\d)EEE", name)
+        m = re.search(r"attn_fwd_stream_kernelI(\w+?)Li(\d+)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)EEE", name)
         assert m, name
-        d, causal, spec, pre, wide = (int(m.group(i)) for i in (2, 3, 4, 5, 6))
+        d, causal, spec, pre, wide, lm = (int(m.group(i)) for i in (2, 3, 4, 5, 6, 7))
         seen += 1
         assert r["sgpr_spill_count"] == 0, (name, r)
         if d == 128:
-            assert r["vgpr_count"] <= 256 and r["vgpr_spill_count"] <= (4 if causal and pre else 0), (name, r)
+            assert r["vgpr_count"] <= 256 and r["vgpr_spill_count"] <= (4 if (causal and pre) or lm else 0), (name, r)
             assert r["group_segment_fixed_size"] <= 160 * 1024, (name, r)
         elif wide:
             assert r["vgpr_count"] <= 256 and r["vgpr_spill_count"] == 0, (name, r)

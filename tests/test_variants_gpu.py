@@ -67,6 +67,12 @@ VARIANTS = [
     (dict(attn_variant=3, attn_spec=1, attn_pre=0), None, LP_ATOL), (dict(attn_variant=3, attn_spec=1, attn_pre=1), None, LP_ATOL),
     (dict(attn_variant=3, attn_spec=1, attn_pre=1, attn_thr=0, attn_wgs=3), None, LP_ATOL),
     (dict(attn_variant=3, attn_spec=1, attn_pre=1, attn_thr=60, attn_wgs=5), None, LP_ATOL),
+    # ... and the speculative softmax whose row sums come out of the matrix cores (sums of the ROUNDED
+    # weights, so a dominant key's rounding cancels in O: the library's choice for unscaled bfloat16
+    # logits at head dims above 64), at its own limit, at limits that send it back often, and on scaled logits
+    (dict(attn_variant=3, attn_spec=2), 1.0, LP_ATOL), (dict(attn_variant=3, attn_spec=2, attn_thr=60), 1.0, LP_ATOL),
+    (dict(attn_variant=3, attn_spec=2, attn_thr=0, attn_wgs=3), 1.0, LP_ATOL), (dict(attn_variant=3, attn_spec=2, attn_thr=5), None, LP_ATOL),
+    (dict(attn_variant=3, attn_spec=2), None, LP_ATOL),
 ]
 
 
@@ -89,13 +95,14 @@ def test_schedules_shapes_and_deferred_max_agree(tuned, knobs, scale, atol, dtyp
     assert _maxdiff(out.float().cpu().numpy(), ref) <= atol
     # with Q pre-multiplied by scale * log2(e) (forced here: the library does not do it when the row
     # statistic is asked for) a logit of 50 moves by up to ~2^-8 of its size, and the statistic with it
-    lse_tol = 6e-2 if knobs.get("attn_pre") == 1 else 2e-3
+    # (and with the row sums taken from the rounded weights, forced here likewise, by 2^-9)
+    lse_tol = 6e-2 if knobs.get("attn_pre") == 1 else 4e-3 if knobs.get("attn_spec") == 2 else 2e-3
     assert _maxdiff(lse.cpu().numpy(), ref_cpu.attention_lse(qr, kr, scale=scale)) <= lse_tol
     # the call without the row statistic (where the library may take a faster route) meets the same bound
     assert _maxdiff(tuned.flash_attn_fwd(qd, kd, vd, scale=scale).float().cpu().numpy(), ref) <= atol
 
 
-@pytest.mark.parametrize("variant,spec", [(1, -1), (2, 0), (2, 1), (3, 0), (3, 1), (3, -1)])
+@pytest.mark.parametrize("variant,spec", [(1, -1), (2, 0), (2, 1), (3, 0), (3, 1), (3, 2), (3, -1)])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("shape", [
@@ -114,7 +121,7 @@ def test_mfma_shapes_vs_oracle(tuned, variant, spec, causal, dtype, shape):
     ref = ref_cpu.attention_bhnd(qr, kr, vr, scale=scale, causal=causal)
     assert bool(torch.isfinite(out.float()).all())
     assert _maxdiff(out.float().cpu().numpy(), ref) <= LP_ATOL
-    assert _maxdiff(lse.cpu().numpy(), ref_cpu.attention_lse(qr, kr, scale=scale, causal=causal)) <= 1e-3
+    assert _maxdiff(lse.cpu().numpy(), ref_cpu.attention_lse(qr, kr, scale=scale, causal=causal)) <= (3e-3 if spec == 2 else 1e-3)
 
 
 @pytest.mark.parametrize("wgs,occ", [(1, 0), (3, 0), (8, 2), (11, 0), (0, 0), (0, 2)])

@@ -9,6 +9,7 @@ run() { local name=$1 secs=$2; shift 2; echo "=== $name ==="; timeout -k 10 "$se
 run ab_headline 200 python -u tools/ab_attn.py "attn_variant=3" "attn_variant=3,lib=$E" "attn_variant=2" --rounds 11
 run ab_ones 200 python -u tools/ab_attn.py "attn_variant=3" "attn_variant=3,lib=$E" --rounds 5 --data ones
 run ab_scale1 200 python -u tools/ab_attn.py "attn_variant=3" "attn_variant=3,lib=$E" --scale 1.0 --rounds 7
+run ab_scale1_spec 200 python -u tools/ab_attn.py "attn_variant=3" "attn_variant=3,attn_spec=1,attn_pre=0,lib=$E" "attn_variant=3,attn_spec=1,attn_pre=0,attn_thr=60,lib=$E" --scale 1.0 --rounds 7
 run ab_causal 200 python -u tools/ab_attn.py "attn_variant=3" "attn_variant=3,lib=$E" --causal --rounds 7
 run ab_d64 200 python -u tools/ab_attn.py "attn_variant=2" "attn_variant=3" "attn_variant=3,lib=$E" --shape 4,32,4096,64 --rounds 7
 exit 0
