@@ -349,8 +349,17 @@ def bench_attention_f32(mfa):
         kt = k.t().contiguous()
         ms = _median_ms(lambda: mfa.my_attention(q, kt, v), iters=30)
         tf = 4.0 * n * n * d / ms / 1e9
-        res.append({"call": f"my_attention N={n} d={d}", "us": round(ms * 1e3, 2), "TFLOP/s": round(tf, 3),
-                    "frac_mfma_f64_f32_peak": round(tf / F32_PEAK_TFLOPS, 4)})
+        # ... and the way the reference times its kernels (benchmark.py:12-20): calls back to back
+        # between two synchronisations, mean per call with launch overhead and the output allocation
+        calls = 1000
+        torch.cuda.synchronize()
+        t0 = time.perf_counter_ns()
+        for _ in range(calls):
+            mfa.my_attention(q, kt, v)
+        torch.cuda.synchronize()
+        b2b = (time.perf_counter_ns() - t0) / calls / 1e3
+        res.append({"call": f"my_attention N={n} d={d}", "us": round(ms * 1e3, 2), "us_per_call_back_to_back": round(b2b, 2),
+                    "TFLOP/s": round(tf, 3), "frac_mfma_f64_f32_peak": round(tf / F32_PEAK_TFLOPS, 4)})
     B, H, N, d = 4, 32, 4096, 128
     q, k, v = (torch.randn(B, H, N, d, device="cuda") for _ in range(3))
     ms = _median_ms(lambda: mfa.flash_attn_fwd(q, k, v, scale=d ** -0.5), iters=5, warm=2)
