@@ -470,16 +470,19 @@ attn_fwd_stream_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, const
         } else if constexpr (SPECULATE) {
             weights();
             if constexpr (LM) {
-                // the lane's largest weight per query stands in for its row sum (which the matrix cores form)
+                // The lane's largest weight per query stands in for its row sum (which the matrix cores form).
+                // Plain fmaxf, not the asm forms used on MFMA results: an instruction the compiler does not
+                // know as a vector instruction gets no wait state behind the v_exp_f32 whose result it
+                // reads (transcendental results arrive a cycle late) and would see the register's old value.
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
-                    float a = vmax3(p[0][qb][0], p[0][qb][1], p[0][qb][2]);
-                    float b = vmax3(p[2][qb][0], p[2][qb][1], p[2][qb][2]);
-                    a = vmax3(a, p[0][qb][3], p[1][qb][0]);
-                    b = vmax3(b, p[2][qb][3], p[3][qb][0]);
-                    a = vmax3(a, p[1][qb][1], p[1][qb][2]);
-                    b = vmax3(b, p[3][qb][1], p[3][qb][2]);
-                    psum[qb] = vmax3(a, b, vmax2(p[1][qb][3], p[3][qb][3]));
+                    float a = __builtin_fmaxf(__builtin_fmaxf(p[0][qb][0], p[0][qb][1]), p[0][qb][2]);
+                    float b = __builtin_fmaxf(__builtin_fmaxf(p[2][qb][0], p[2][qb][1]), p[2][qb][2]);
+                    a = __builtin_fmaxf(__builtin_fmaxf(a, p[0][qb][3]), p[1][qb][0]);
+                    b = __builtin_fmaxf(__builtin_fmaxf(b, p[2][qb][3]), p[3][qb][0]);
+                    a = __builtin_fmaxf(__builtin_fmaxf(a, p[1][qb][1]), p[1][qb][2]);
+                    b = __builtin_fmaxf(__builtin_fmaxf(b, p[3][qb][1]), p[3][qb][2]);
+                    psum[qb] = __builtin_fmaxf(__builtin_fmaxf(a, b), __builtin_fmaxf(p[1][qb][3], p[3][qb][3]));
                 }
             }
             // negated comparisons: a NaN or an infinite sum goes back too

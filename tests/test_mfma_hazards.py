@@ -56,3 +56,28 @@ def test_backward_kernels_keep_the_result_latency():
     seen, bad = chk.check(asm)
     assert seen >= 8 * 32, "the kernels' hand-written MFMAs were not found in the assembly"
     assert bad == [], "\n".join(bad[:10])
+
+
+def test_trans_use_checker():
+    asm = "_Z1kv:\n\tv_exp_f32_e32 v5, v1\n\tv_max3_f32 v9, v5, v6, v7\n"
+    assert chk.check_trans_use(asm) == (1, chk.check_trans_use(asm)[1]) and len(chk.check_trans_use(asm)[1]) == 1
+    assert chk.check_trans_use("_Z1kv:\n\tv_exp_f32_e32 v5, v1\n\ts_nop 0\n\tv_max3_f32 v9, v5, v6, v7\n")[1] == []
+    assert chk.check_trans_use("_Z1kv:\n\tv_exp_f32_e32 v5, v1\n\tv_add_f32_e32 v9, v6, v7\n\tv_mul_f32_e32 v2, v5, v5\n")[1] == []
+    assert chk.check_trans_use("_Z1kv:\n\tv_exp_f32_e32 v5, v1\n\tv_exp_f32_e32 v5, v2\n")[1] == []      # overwritten, not read
+    assert len(chk.check_trans_use("_Z1kv:\n\tv_rcp_f32_e32 v5, v1\n\tv_fma_f32 v0, v[4:7], v2, v3\n")[1]) == 1
+
+
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="needs hipcc")
+@pytest.mark.parametrize("src,min_mfmas", [("attn_fwd_stream.hip", 0), ("attn_fwd_mfma16.hip", 0), ("attn_fwd_mfma256.hip", 8 * 48),
+                                           ("attn_bwd_mfma.hip", 8 * 32), ("attn_bwd_wide.hip", 0)])
+def test_attention_kernels_keep_both_rules(src, min_mfmas):
+    """Every attention source with inline asm beside transcendental instructions or with hand-written
+    MFMAs: no early reader of an MFMA result, and no instruction reading a transcendental result one
+    issue slot behind it (an asm max on fresh exp2 results did exactly that in one build of the
+    resident-workgroup forward: its go-back test read stale registers, float16 weights overflowed)."""
+    build = _load("myfa_build", os.path.join(ROOT, "flash-attention_amd", "build.py"))
+    asm = chk.compile_to_asm(os.path.join(build.CSRC, src), build.PER_SOURCE_FLAGS.get(src, []))
+    seen, bad = chk.check(asm)
+    assert seen >= min_mfmas and bad == [], "\n".join(bad[:10])
+    tseen, tbad = chk.check_trans_use(asm)
+    assert tseen > 0 and tbad == [], "\n".join(tbad[:10])

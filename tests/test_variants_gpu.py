@@ -102,6 +102,32 @@ def test_schedules_shapes_and_deferred_max_agree(tuned, knobs, scale, atol, dtyp
     assert _maxdiff(tuned.flash_attn_fwd(qd, kd, vd, scale=scale).float().cpu().numpy(), ref) <= atol
 
 
+@pytest.mark.parametrize("dtype,thr", [(torch.float16, -1), (torch.float16, 15), (torch.bfloat16, -1), (torch.bfloat16, 12)])
+def test_matrix_core_row_sums_go_back_in_time(tuned, dtype, thr):
+    """Unscaled logits at N = 4096: some row's max jumps by more than the limit in a late tile, so the
+    go-back test of the speculative softmax with matrix-core row sums (attn_spec = 2) decides whether
+    a float16 weight overflows.  Finite, inside the bound on sampled rows, and the same bits on a
+    second run (the test once read exp2 results one issue slot early: non-finite rows that changed
+    from run to run)."""
+    B, H, N, d = 1, 4, 4096, 128
+    torch.manual_seed(1)
+    q, k, v = (torch.randn(B, H, N, d, dtype=dtype, device="cuda") for _ in range(3))
+    tuned.set(attn_variant=3, attn_spec=2, attn_thr=thr)
+    out = tuned.flash_attn_fwd(q, k, v, scale=1.0)
+    again = tuned.flash_attn_fwd(q, k, v, scale=1.0)
+    assert bool(torch.isfinite(out.float()).all())
+    assert torch.equal(out, again)
+    rows = torch.arange(0, N, 37)
+    for h in range(H):
+        qr, kr, vr = q[0, h, rows].float().cpu().numpy(), k[0, h].float().cpu().numpy(), v[0, h].float().cpu().numpy()
+        # float64 softmax(q k^T) v of the sampled rows against all keys (ref_cpu.attention_naive's math on a
+        # rectangular problem)
+        sc = qr.astype(np.float64) @ kr.astype(np.float64).T
+        w = np.exp(sc - sc.max(axis=1, keepdims=True))
+        ref = (w / w.sum(axis=1, keepdims=True)) @ vr.astype(np.float64)
+        assert _maxdiff(out[0, h, rows].float().cpu().numpy(), ref) <= LP_ATOL
+
+
 @pytest.mark.parametrize("variant,spec", [(1, -1), (2, 0), (2, 1), (3, 0), (3, 1), (3, 2), (3, -1)])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

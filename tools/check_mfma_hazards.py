@@ -17,6 +17,9 @@ assembly and verifies the outcome on every kernel:
 
     python tools/check_mfma_hazards.py flash-attention_amd/csrc/attn_bwd_mfma.hip [extra hipcc flags]
 
+The same run checks a second rule the compiler cannot keep for inline asm (`check_trans_use`): no
+instruction reads the result of a transcendental instruction issued immediately in front of it.
+
 Exit status 0 and a one-line summary if every kernel passes; 1 and the offending lines otherwise.
 """
 import os
@@ -98,13 +101,49 @@ def check(asm):
     return seen, bad
 
 
+TRANS = ("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_")
+
+
+def check_trans_use(asm):
+    """A second rule of the same kind.  The result of a transcendental instruction (v_exp_f32 and its
+    kin) arrives one issue slot late: the compiler puts a wait state (or another instruction) between
+    such an instruction and a vector instruction that reads its result -- but only for instructions
+    it knows; the text of an inline asm statement gets none.  Returns (transcendental instructions
+    seen, violations): an instruction that names the result register of the instruction issued
+    immediately in front of it, when that one is transcendental."""
+    seen, bad = 0, []
+    kernel, prev = None, None       # prev = (result registers, text) of the last issued instruction if transcendental
+    for n, line in enumerate(asm.split("\n"), 1):
+        s = line.strip()
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            kernel, prev = m.group(1), None
+            continue
+        if not s or s.startswith((";", ".", "//")) or s.endswith(":"):
+            continue
+        code = s.split(";")[0]
+        ops = code.split(None, 1)[1] if " " in code else ""
+        if prev is not None and code.startswith("v_"):
+            srcs = vregs(",".join(ops.split(",")[1:]))
+            if srcs & prev[0]:
+                bad.append(f"{kernel}: line {n}: `{code.strip()}` reads the result of `{prev[1].strip()}` issued right in front of it")
+        prev = None
+        if code.startswith(TRANS):
+            seen += 1
+            prev = (vregs(ops.split(",")[0]), code)
+    return seen, bad
+
+
 def main():
     src = sys.argv[1]
-    seen, bad = check(compile_to_asm(src, sys.argv[2:]))
-    for b in bad:
+    asm = compile_to_asm(src, sys.argv[2:])
+    seen, bad = check(asm)
+    tseen, tbad = check_trans_use(asm)
+    for b in bad + tbad:
         print(b)
-    print(f"{os.path.basename(src)}: {seen} hand-written MFMAs, {len(bad)} result-latency violations")
-    return 1 if bad or not seen else 0
+    print(f"{os.path.basename(src)}: {seen} hand-written MFMAs, {len(bad)} result-latency violations; "
+          f"{tseen} transcendental instructions, {len(tbad)} read one slot behind")
+    return 1 if bad or tbad or not seen else 0
 
 
 if __name__ == "__main__":
