@@ -45,6 +45,34 @@ def vregs(text):
 
 
 def compile_to_asm(src, extra):
+    """gfx950 assembly of `src` (device side).  Kept in a per-user cache under the temp directory,
+    keyed by the contents of the source, of every header beside it and the flags: several checks
+    read the same listing and a compile takes up to a minute."""
+    import glob
+    import hashlib
+    h = hashlib.sha256(" ".join(extra).encode())
+    csrc = os.path.dirname(os.path.abspath(src))
+    for f in [src] + sorted(glob.glob(os.path.join(csrc, "*.h"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    cache_dir = os.path.join(tempfile.gettempdir(), f"myfa_asm_cache_{os.getuid()}")
+    cached = os.path.join(cache_dir, os.path.basename(src) + "." + h.hexdigest()[:24] + ".s")
+    if os.path.exists(cached):
+        with open(cached) as f:
+            return f.read()
+    text = _compile_to_asm(src, extra)
+    try:
+        os.makedirs(cache_dir, exist_ok=True)
+        tmp = cached + f".{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
+            f.write(text)
+        os.replace(tmp, cached)
+    except OSError:
+        pass
+    return text
+
+
+def _compile_to_asm(src, extra):
     hipcc = "/opt/rocm/bin/hipcc"
     out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
