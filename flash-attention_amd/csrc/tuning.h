@@ -23,7 +23,9 @@ struct Tuning {
     // recurrence); < 0 = the library's choice per kernel and element type
     float attn_thr = -1.f;
     // 16x16x32 build: 1 = weights formed against the standing max, the max looked for only when a row
-    // sum passes 2^attn_thr; 0 = the max of every tile, vote on its growth; -1 = the library's choice
+    // sum passes 2^attn_thr; 0 = the max of every tile, vote on its growth; -1 = the library's choice;
+    // 2 (resident-workgroup build, head dims above 64, no mask) = as 1 with the row sums formed by the
+    // matrix cores from the rounded weights and the go-back test on the largest weight
     int attn_spec = -1;
     // timing probes of the stamped 16x16x32 build (wrong results): 8 = no tile fetches in the loop,
     // 16 = no vector phase
