@@ -318,13 +318,23 @@ attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, co
                 constexpr int i = decltype(ic)::value;
                 lgkm_wait(IC<2 * (NPV - 1 - i < FW - 1 ? NPV - 1 - i : FW - 1)>{});
                 const s16x8 a = win[i % FW];
+                // The wave issues in order and an MFMA holds the issue of the next one for its 32 cycles:
+                // the step's other instructions are dealt BETWEEN its MFMAs, the fragment request and half
+                // the weights behind the first, the rest behind the last (all of them behind the last
+                // MFMA cost 16 cycles per step: they no longer fit one MFMA's shadow).
+                // (Behind the last tile the weights work on stale registers and nothing reads the results.)
+                constexpr int EA = (EP + QB - 1) / QB;    // weights per MFMA of the step
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) M::acc_a(a, pb[qb][i / DB], o[qb][i % DB]);
-                if constexpr (i + FW < NPV) win[i % FW] = v_frag(a0, a1, IC<i + FW>{});
-                // (behind the last tile these work on stale registers and nothing reads the results)
+                for (int qb = 0; qb < QB; ++qb) {
+                    M::acc_a(a, pb[qb][i / DB], o[qb][i % DB]);
+                    if (qb == 0) {
+                        if constexpr (i + FW < NPV) win[i % FW] = v_frag(a0, a1, IC<i + FW>{});
+                    }
 #pragma unroll
-                for (int e = 0; e < EP; ++e)
-                    if (EP * i + e < 16 * QB) weight(EP * i + e);
+                    for (int e = EA * qb; e < EA * (qb + 1) && e < EP; ++e)
+                        if (EP * i + e < 16 * QB) weight(EP * i + e);
+                    if (qb + 1 < QB) __builtin_amdgcn_sched_barrier(0);
+                }
                 // The fetches of K(t+3), V(t+2) are spread over the stream's last steps; the wait in front
                 // confirms this wave's pieces of K(t+2) and V(t+1), issued an iteration ago.
                 constexpr int S0 = NPV - FW, PPS = (2 * LPT + FW - 1) / FW;

@@ -1,10 +1,11 @@
 #!/bin/bash
-# GPU box: attention tests (all head dims, causal, fuzz, backward uses the forward's lse), then the wide
-# forward against the previous build of it (exp_oldwide.so)
+# GPU box: attention tests that touch the wide forward, then the wide forward against another build of the
+# library (my_flash_attn_cuda/exp_<name>.so, default "prev": python flash-attention_amd/build.py --exp prev)
+name=${1:-prev}
 mkdir -p gpurun_out/wide
-timeout -k 10 900 python -u -m pytest tests/test_attention_gpu.py tests/test_attention_causal_gpu.py tests/test_fuzz_gpu.py tests/test_attention_bwd_gpu.py -x -q --timeout 180 --timeout-method thread > gpurun_out/wide/tests.log 2>&1
-rc=$?; tail -8 gpurun_out/wide/tests.log; [ $rc -ne 0 ] && exit $rc
-OLD=flash-attention_amd/my_flash_attn_cuda/exp_oldwide.so
+timeout -k 10 900 python -u -m pytest tests/test_attention_gpu.py tests/test_attention_causal_gpu.py tests/test_fuzz_gpu.py -x -q --timeout 180 --timeout-method thread > gpurun_out/wide/tests.log 2>&1
+rc=$?; tail -4 gpurun_out/wide/tests.log; [ $rc -ne 0 ] && exit $rc
+OLD=flash-attention_amd/my_flash_attn_cuda/exp_$name.so
 for sh in 4,16,4096,256 4,16,4096,192 2,8,8192,256; do
   echo "== $sh"; timeout -k 10 200 python tools/ab_attn.py "attn_variant=-1" "attn_variant=-1,lib=$OLD" --shape $sh || exit 1
 done
