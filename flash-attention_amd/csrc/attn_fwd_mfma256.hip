@@ -190,7 +190,9 @@ attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, co
         asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
     };
     // S^T of one tile: key (i & 3) + 8 (i >> 2) + 4 h of the tile in register i
-    auto s_stream = [&](int kbuf) __attribute__((always_inline)) {
+    // `after(i)` runs between the two MFMAs of step i (the loop hangs the tile fetches there: the
+    // stream has issue slots to spare, the other one's are taken by the weights)
+    auto s_stream = [&](int kbuf, auto&& after) __attribute__((always_inline)) {
         const unsigned a0 = lds0 + kbuf * TILE_B + rbase[0], a1 = lds0 + kbuf * TILE_B + rbase[1];
         s16x8 win[FW];
         static_for<FW>([&](auto ic) __attribute__((always_inline)) { win[decltype(ic)::value] = k_frag(a0, a1, ic); });
@@ -203,8 +205,11 @@ attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, co
                 // pinned to vector registers (the accumulator file belongs to O^T)
                 if constexpr (i == 0) M::first_v(a, qf[qb][0], s[qb]);
                 else M::acc_v(a, qf[qb][i], s[qb]);
+                if (qb == 0) {
+                    if constexpr (i + FW < KS) win[i % FW] = k_frag(a0, a1, IC<i + FW>{});
+                    after(ic);
+                }
             }
-            if constexpr (i + FW < KS) win[i % FW] = k_frag(a0, a1, IC<i + FW>{});
             __builtin_amdgcn_sched_barrier(0);
         });
         mfma_drain();
@@ -292,7 +297,7 @@ attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, co
 
     // tile 0 on its own: nothing to run under yet
     {
-        s_stream(0);
+        s_stream(0, [](auto) __attribute__((always_inline)) {});
         look(0);
 #pragma unroll
         for (int e = 0; e < 16 * QB; ++e) weight(e);
@@ -307,7 +312,14 @@ attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, co
     for (int t = 0; t < ntiles; ++t) {
         const bool more = t + 1 < ntiles;          // uniform
         if (more) {
-            s_stream(kc);
+            // The fetches of K(t+3), V(t+2) -- into the buffers K(t), V(t-1) were read from an iteration ago --
+            // go out one piece every other step of this stream.  Nothing orders them against the
+            // fragment reads but the barriers (the reads are asm, the compiler adds no wait).
+            s_stream(kc, [&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                static_assert(2 * (2 * LPT) <= KS, "a piece every other step");
+                if constexpr (i % 2 == 1 && i / 2 < 2 * LPT) fetch_piece(tile_or_end(t + 3), kf, tile_or_end(t + 2), vf, i / 2);
+            });
             look((t + 1) * TR);
         }
         {
@@ -335,17 +347,11 @@ attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, co
                         if (EP * i + e < 16 * QB) weight(EP * i + e);
                     if (qb + 1 < QB) __builtin_amdgcn_sched_barrier(0);
                 }
-                // The fetches of K(t+3), V(t+2) are spread over the stream's last steps; the wait in front
-                // confirms this wave's pieces of K(t+2) and V(t+1), issued an iteration ago.
-                constexpr int S0 = NPV - FW, PPS = (2 * LPT + FW - 1) / FW;
-                if constexpr (i == S0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if constexpr (i >= S0) {
-#pragma unroll
-                    for (int e = 0; e < PPS; ++e) {
-                        const int p = PPS * (i - S0) + e;
-                        if (p < 2 * LPT) fetch_piece(tile_or_end(t + 3), kf, tile_or_end(t + 2), vf, p);
-                    }
-                }
+                // Late in the stream: this wave's pieces of K(t+2) and V(t+1), issued an iteration ago, are
+                // in (all but the 2 LPT fetches of this iteration; the loop holds no other vector-memory
+                // operation -- tests/test_kernel_resources.py checks that it spills nothing).  Behind the
+                // last tile's stream nothing was issued and nothing is waited for or needed.
+                if constexpr (i == NPV - FW) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * LPT) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
@@ -359,6 +365,7 @@ attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, co
         const int vw = vc; vc = vn; vn = vf; vf = vw;
     }
 
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no fetch may still be writing LDS when the wave ends
     // ---- epilogue: O = O^T / l, written as rows; lane (r,h) holds, for its query,
     // d = 32db + 8g + 4h + (0..3) in registers 4g..4g+3 of block db
     mfma_drain();
