@@ -37,7 +37,9 @@ finds is the --gpus it was asked for.  Every rank runs the same per-GPU workload
                    TFLOP/s = 35.18 TFLOP / max-over-ranks time per pass -- emitted for every --gpus N
   config3 / headline_scale_one  configs[2] (f16 B8 H16 N1024 d64) and the headline shape with the
                    reference's unscaled logits (scale = 1.0), N = 1 only
-  wide_head_dim    bf16 B4 H16 N4096 d256 (the 256-column build for head dims above 128), N = 1 only
+  wide_head_dim    bf16 B4 H16 N4096 d256 (the 256-column build for head dims above 128), N = 1 only;
+                   wide_head_dim_backward: its backward (2.5x the forward's algorithmic flops) beside
+                   PyTorch's scaled_dot_product_attention backward
   power_context    the same attention launch on all-ones operands, and the vendor bf16 GEMM
                    (torch.matmul -> hipBLASLt, 8192^3) on random and all-ones operands: the chip
                    lowers its clock under the power limit when operands are random, so these
@@ -642,6 +644,7 @@ def main():
         result["config3"] = bench_shape(mfa, 8, 16, 1024, 64, torch.float16, 64 ** -0.5, iters=100)
         result["config3_scale_one"] = bench_shape(mfa, 8, 16, 1024, 64, torch.float16, 1.0, iters=100)
         result["wide_head_dim"] = bench_shape(mfa, 4, 16, 4096, 256, torch.bfloat16, 256 ** -0.5, iters=10)
+        result["wide_head_dim_backward"] = bench_backward(mfa, 4, 16, 4096, 256, torch.bfloat16, 256 ** -0.5)
         result["power_context"] = power_context(mfa, B, H, N, d, dtype, scale)
         result["attention_f32"] = bench_attention_f32(mfa)
         result["attention_backward"] = bench_backward(mfa, B, H, N, d, dtype, scale)
