@@ -195,16 +195,21 @@ attn_bwd_dq_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
                 if (i / KS) dp = M::run(a, dof[i % KS], dp);
                 else s = M::run(a, qf[i % KS], s);
                 if (i + FW < 2 * KS) win[i % FW] = fb.row((i + FW) / KS ? Vb : Kb, (i + FW) % KS);
+                // P needs S only: its scale-subtract and exp2 run, two elements a step, in the shadow of
+                // the MFMAs of dP^T (from the third on: S's last MFMA has to land first)
+                if (i >= KS + 2) {
+#pragma unroll
+                    for (int e = 2 * (i - KS - 2); e < 2 * (i - KS - 2) + 2; ++e)
+                        if (e < 16) s[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], sl2, -lse2));
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        static_assert(2 * (KS - 2) >= 16, "every element of P is formed under the dP stream");
         // accumulator register i is key kv0 + (i & 3) + 8 (i >> 2) + 4 h of the lane's query
         const bool edge = kv0 + TR > N || (CAUSAL && kv0 + TR - 1 > q0 + 32 * wave);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], sl2, -lse2));
-            s[i] = p * (dp[i] + ndelta);
-        }
+        for (int i = 0; i < 16; ++i) s[i] *= dp[i] + ndelta;
         if (edge) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -387,9 +392,17 @@ attn_bwd_dkv_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, con
                 if (i / KS) { if constexpr (!DV) dp = M::run(a, vf[i % KS], dp); }
                 else s = M::run(a, kf[i % KS], s);
                 if (i + FW < NA) win[i % FW] = fb.row((i + FW) / KS ? dOb : Qb, (i + FW) % KS);
+                // dK pass: P needs S only, so it is formed in the shadow of the MFMAs of dP (from the
+                // third on: S's last MFMA has to land first), two elements a step
+                if (!DV && i >= KS + 2) {
+#pragma unroll
+                    for (int e = 2 * (i - KS - 2); e < 2 * (i - KS - 2) + 2; ++e)
+                        if (e < 16) s[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], sl2, -l4[e >> 2][e & 3]));
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        static_assert(2 * (KS - 2) >= 16, "every element of P is formed under the dP stream");
         // pairs (query, key) outside the problem or above the diagonal: element c = 8 (i >> 2) + (i & 3)
         // of this lane is masked iff c >= c_hi or c < c_lo
         const bool edge = qt0 + TR > N || k0 + BK > N || (CAUSAL && qt0 < k0 + BK);
@@ -397,9 +410,8 @@ attn_bwd_dkv_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, con
         const int c_lo = CAUSAL ? krow - (qt0 + 4 * h) : -(1 << 30);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], sl2, -l4[i >> 2][i & 3]));
-            if constexpr (DV) s[i] = p;
-            else s[i] = p * dp[i];
+            if constexpr (DV) s[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], sl2, -l4[i >> 2][i & 3]));
+            else s[i] *= dp[i];
         }
         if (edge) {
 #pragma unroll
