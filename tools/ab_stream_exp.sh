@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-3 experiment J (GPU box): in-tree tuning library against an experiment build (my_flash_attn_cuda/exp_<name>.so) of variant 3.
+# GPU box: in-tree tuning library against an experiment build (my_flash_attn_cuda/exp_<name>.so) of variant 3.
 set -u
 name=${1:-addr}
-mkdir -p gpurun_out/r3j
-o=gpurun_out/r3j
+mkdir -p gpurun_out/ab_stream
+o=gpurun_out/ab_stream
 E=flash-attention_amd/my_flash_attn_cuda/exp_$name.so
 run() { local name=$1 secs=$2; shift 2; echo "=== $name ==="; timeout -k 10 "$secs" "$@" > "$o/$name.log" 2>&1; local rc=$?; grep -v amdgpu.ids "$o/$name.log" | tail -n 8; echo "=== $name exit $rc ==="; if [ $rc -ne 0 ]; then exit $rc; fi; }
 run ab_headline 200 python -u tools/ab_attn.py "attn_variant=3" "attn_variant=3,lib=$E" "attn_variant=2" --rounds 11
