@@ -64,7 +64,8 @@ def test_fuzz_forward_f32(mfa, case):
     assert np.abs(lse.cpu().numpy() - ref_cpu.attention_lse(q.numpy(), k.numpy(), scale=scale * 0.5, causal=causal)).max() <= 1e-5
 
 
-@pytest.mark.parametrize("case", _cases(13, 16, [64, 128]) + _cases(16, 8, [32, 96, 40]))
+# (192 and 256: the four-wave builds; the other dims above 128 are zero-padded up to those)
+@pytest.mark.parametrize("case", _cases(13, 16, [64, 128]) + _cases(16, 8, [32, 96, 40]) + _cases(18, 14, [192, 256, 136, 200, 248]))
 def test_fuzz_backward(mfa, case):
     B, H, N, d, causal, _, seed = case
     scale = d ** -0.5
