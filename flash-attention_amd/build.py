@@ -27,7 +27,7 @@ LIB = os.path.join(PKG, "libmyfa_gfx950.so")
 LIB_TUNING = os.path.join(PKG, "libmyfa_gfx950_tuning.so")
 
 SOURCES = ["c_abi.hip", "softmax_rows.hip", "softmax_strided.hip", "attn_fwd_f32.hip", "attn_fwd_dispatch.hip", "attn_fwd_mfma.hip",
-           "attn_fwd_mfma16.hip", "attn_fwd_stream.hip", "attn_fwd_mfma256.hip", "attn_bwd_mfma.hip", "attn_bwd_wide.hip", "matmul_f32.hip"]
+           "attn_fwd_mfma16.hip", "attn_fwd_stream.hip", "attn_fwd_mfma256.hip", "attn_bwd_mfma.hip", "attn_bwd_wide.hip", "attn_bwd_f32.hip", "matmul_f32.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I" + INCLUDE, "-I" + CSRC,
          "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]

@@ -744,22 +744,29 @@ int attn_bwd_mfma_static_ws(const void* q, const void* k, const void* v, const v
 int attn_bwd_wide(const void* q, const void* k, const void* v, const void* o, const float* lse, const void* dout,
                   void* dq, void* dk, void* dv, float* delta, int64_t heads, int64_t N, int64_t d,
                   float scale, int dtype, bool causal, hipStream_t s);   // attn_bwd_wide.hip
+int attn_bwd_f32(const float* q, const float* k, const float* v, const float* o, const float* lse, const float* dout,
+                 float* dq, float* dk, float* dv, float* delta, int64_t heads, int64_t N, int64_t d,
+                 float scale, bool causal, hipStream_t s);               // attn_bwd_f32.hip
 
 // dtype: MYFA_F16 or MYFA_BF16; d: 64, 128 (this file's kernels), 192 or 256 (attn_bwd_wide.hip);
-// heads = B*H.  `delta` is a caller-provided float32 workspace of 2 * heads * N elements (the
+// or MYFA_F32 with any d up to 256 (attn_bwd_f32.hip).  heads = B*H.  `delta` is a caller-provided float32 workspace of 2 * heads * N elements (the
 // library allocates nothing).
 int attn_bwd_mfma(const void* q, const void* k, const void* v, const void* o, const float* lse, const void* dout,
                   void* dq, void* dk, void* dv, float* delta, int64_t heads, int64_t N, int64_t d,
                   float scale, int dtype, bool causal, hipStream_t s) {
     if (!(scale > 0.f)) return fail(MYFA_E_UNSUPPORTED, "attention backward: scale must be > 0, got %g", (double)scale);
     if (N > 0x7fffffffLL / 256) return fail(MYFA_E_UNSUPPORTED, "attention backward: N=%lld too large", (long long)N);
+    if (dtype == MYFA_F32)
+        return attn_bwd_f32(static_cast<const float*>(q), static_cast<const float*>(k), static_cast<const float*>(v),
+                            static_cast<const float*>(o), lse, static_cast<const float*>(dout), static_cast<float*>(dq),
+                            static_cast<float*>(dk), static_cast<float*>(dv), delta, heads, N, d, scale, causal, s);
     if ((dtype == MYFA_BF16 || dtype == MYFA_F16) && (d == 192 || d == 256))
         return attn_bwd_wide(q, k, v, o, lse, dout, dq, dk, dv, delta, heads, N, d, scale, dtype, causal, s);
     if (dtype == MYFA_BF16 && d == 128) return launch_bwd<__bf16, 128>(q, k, v, o, lse, dout, dq, dk, dv, delta, heads, N, scale, causal, s);
     if (dtype == MYFA_BF16 && d == 64)  return launch_bwd<__bf16, 64>(q, k, v, o, lse, dout, dq, dk, dv, delta, heads, N, scale, causal, s);
     if (dtype == MYFA_F16 && d == 128)  return launch_bwd<_Float16, 128>(q, k, v, o, lse, dout, dq, dk, dv, delta, heads, N, scale, causal, s);
     if (dtype == MYFA_F16 && d == 64)   return launch_bwd<_Float16, 64>(q, k, v, o, lse, dout, dq, dk, dv, delta, heads, N, scale, causal, s);
-    return fail(MYFA_E_UNSUPPORTED, "attention backward: needs float16 or bfloat16 and head dim 64, 128, 192 or 256 (got dtype %d, d %lld)", dtype, (long long)d);
+    return fail(MYFA_E_UNSUPPORTED, "attention backward: needs float16 or bfloat16 with head dim 64, 128, 192 or 256, or float32 with head dim up to 256 (got dtype %d, d %lld)", dtype, (long long)d);
 }
 
 }  // namespace myfa

@@ -193,8 +193,8 @@ int myfa_attn_bwd_bhnd(const void* q, const void* k, const void* v, const void* 
     if (B == 0 || H == 0 || N == 0 || d == 0) return MYFA_OK;
     if (!q || !k || !v || !o || !lse || !dout || !dq || !dk || !dv || !delta_ws)
         return fail(MYFA_E_INVALID, "attention backward: null pointer");
-    if (dtype != MYFA_F16 && dtype != MYFA_BF16)
-        return fail(MYFA_E_UNSUPPORTED, "attention backward: float16 or bfloat16 only (dtype tag %d)", dtype);
+    if (dtype != MYFA_F16 && dtype != MYFA_BF16 && dtype != MYFA_F32)
+        return fail(MYFA_E_UNSUPPORTED, "attention backward: float16, bfloat16 or float32 (dtype tag %d)", dtype);
     if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
          reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dq) |
          reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv)) % 16 != 0)
@@ -213,8 +213,8 @@ int myfa_attn_bwd_bhnd_static_ws(const void* q, const void* k, const void* v, co
     if (B == 0 || H == 0 || N == 0 || d == 0) return MYFA_OK;
     if (!q || !k || !v || !o || !lse || !dout || !dq || !dk || !dv)
         return fail(MYFA_E_INVALID, "attention backward: null pointer");
-    if (dtype != MYFA_F16 && dtype != MYFA_BF16)
-        return fail(MYFA_E_UNSUPPORTED, "attention backward: float16 or bfloat16 only (dtype tag %d)", dtype);
+    if (dtype != MYFA_F16 && dtype != MYFA_BF16 && dtype != MYFA_F32)
+        return fail(MYFA_E_UNSUPPORTED, "attention backward: float16, bfloat16 or float32 (dtype tag %d)", dtype);
     if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
          reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dq) |
          reinterpret_cast<uintptr_t>(dk) | reinterpret_cast<uintptr_t>(dv)) % 16 != 0)

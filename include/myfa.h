@@ -223,7 +223,9 @@ const char* myfa_attn_fwd_bhnd_kernel(int64_t d, int dtype, int flags);
 
 /*
  * Backward of myfa_attn_fwd_bhnd_ex for MYFA_F16 / MYFA_BF16, d in {64, 128, 192, 256}
- * (192 and 256: four-wave workgroups on 32-row tiles, dK and dV in separate launches):
+ * (192 and 256: four-wave workgroups on 32-row tiles, dK and dV in separate launches), and for
+ * MYFA_F32 with any d up to 256 (float32 matrix instructions, float32 throughout; B*H <= 65528 and
+ * N*d < 2^31 as in the float32 forward):
  * given the forward's inputs, its output `o`, its row log-sum-exp `lse` and the
  * gradient `dout` of the output, writes dq, dk, dv (same shape and dtype as q, k, v).
  * `delta_ws` is a float32 workspace of 2*B*H*N elements provided by the caller (it

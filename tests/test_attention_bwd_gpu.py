@@ -251,11 +251,84 @@ def test_bwd_causal_headline_shape(mfa):
             assert ours <= max(2.0 * torchs, 2e-2), (nm, ours, torchs)
 
 
+# ---- float32: float32 matrix instructions, any head dim up to 256, any N
+#
+# Tolerance: max |g - g_oracle| <= 2e-5 * max(|g_oracle|, 1) against the float64 oracle on the same
+# float32 inputs (the kernel recomputes exp(scale * S - lse) in float32: an error of a few 1e-6 in
+# a logit of magnitude 30 is a relative error of that size in the weight).
+
+F32_BWD_TOL = 2e-5
+
+
+def _f32_bwd_check(mfa, shape, scale, causal, seed=0):
+    B, H, N, d = shape
+    torch.manual_seed(seed + 97 * N + d)
+    q, k, v, do = (torch.randn(B, H, N, d, dtype=torch.float32) for _ in range(4))
+    got = _run(mfa, q, k, v, do, torch.float32, scale, causal)
+    ref = ref_cpu.attention_bwd_bhnd(q.numpy(), k.numpy(), v.numpy(), do.numpy(), scale=scale, causal=causal)
+    for nm, a, r in zip(("dq", "dk", "dv"), got, ref):
+        assert a.shape == shape and a.dtype == torch.float32
+        err = np.abs(a.cpu().numpy().astype(np.float64) - r).max()
+        assert err <= F32_BWD_TOL * max(np.abs(r).max(), 1.0), (nm, shape, causal, err, np.abs(r).max())
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("shape", [(2, 2, 128, 64), (1, 3, 256, 128), (1, 2, 200, 64), (2, 1, 77, 128), (1, 1, 130, 32),
+                                   (1, 2, 64, 16), (1, 1, 1, 64), (1, 1, 17, 8), (1, 2, 300, 256), (1, 1, 96, 192)])
+def test_bwd_f32_vs_oracle(mfa, shape, causal):
+    _f32_bwd_check(mfa, shape, shape[-1] ** -0.5, causal)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("shape", [(1, 2, 99, 20), (1, 1, 65, 63), (1, 1, 129, 65), (2, 1, 50, 1), (1, 1, 33, 99),
+                                   (1, 1, 80, 130), (1, 1, 40, 250), (1, 1, 2, 2)])
+def test_bwd_f32_ragged_head_dims(mfa, shape, causal):
+    """Head dims that are no multiple of 4 or 16 (the reference's own test dims among them,
+    tests/test_flash_attn.py:155): scalar loads, zero-filled fragments, guarded stores."""
+    _f32_bwd_check(mfa, shape, shape[-1] ** -0.5, causal)
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 256, 64), (1, 1, 192, 128)])
+def test_bwd_f32_unscaled_logits(mfa, shape):
+    """scale = 1.0, the reference's semantics: logits of magnitude ~ 3 sqrt(d)."""
+    _f32_bwd_check(mfa, shape, 1.0, False)
+    _f32_bwd_check(mfa, shape, 1.0, True)
+
+
+def test_autograd_function_f32(mfa):
+    """flash_attn_func differentiates float32 inputs: against autograd of PyTorch's float64
+    attention on the same values."""
+    torch.manual_seed(5)
+    B, H, N, d = 2, 2, 150, 72
+    q, k, v = (torch.randn(B, H, N, d, device="cuda", requires_grad=True) for _ in range(3))
+    do = torch.randn(B, H, N, d, device="cuda")
+    out = mfa.flash_attn_func(q, k, v, scale=d ** -0.5, causal=True)
+    got = torch.autograd.grad(out, (q, k, v), do)
+    qd, kd, vd = (x.detach().double().requires_grad_(True) for x in (q, k, v))
+    ref_out = torch.nn.functional.scaled_dot_product_attention(qd, kd, vd, is_causal=True, scale=d ** -0.5)
+    ref = torch.autograd.grad(ref_out, (qd, kd, vd), do.double())
+    for a, r in zip(got, ref):
+        assert float((a.double() - r).abs().max()) <= F32_BWD_TOL * max(float(r.abs().max()), 1.0)
+
+
+def test_bwd_into_f32(mfa):
+    """The entry point without a workspace argument serves float32 as well, bit for bit."""
+    torch.manual_seed(6)
+    B, H, N, d = 1, 2, 100, 40
+    q, k, v, do = (torch.randn(B, H, N, d, device="cuda") for _ in range(4))
+    out, lse = mfa.flash_attn_fwd(q, k, v, scale=0.2, return_lse=True)
+    want = mfa.flash_attn_bwd(do, q, k, v, out, lse, scale=0.2)
+    dq, dk, dv = (torch.full_like(q, float("nan")) for _ in range(3))
+    mfa.flash_attn_bwd_into(do, q, k, v, out, lse, dq, dk, dv, scale=0.2)
+    for a, b in zip((dq, dk, dv), want):
+        assert torch.equal(a, b)
+
+
 def test_bwd_errors(mfa):
     q = torch.randn(1, 1, 64, 64, device="cuda", dtype=torch.float32)
     lse = torch.zeros(1, 1, 64, device="cuda")
-    with pytest.raises(RuntimeError, match="float16 and bfloat16"):
-        mfa.flash_attn_bwd(q, q, q, q, q, lse)
+    with pytest.raises(RuntimeError, match="float16, bfloat16 and float32"):
+        mfa.flash_attn_bwd(*(q.double() for _ in range(5)), lse)
     qb = q.bfloat16()
     with pytest.raises(RuntimeError, match="lse"):
         mfa.flash_attn_bwd(qb, qb, qb, qb, qb, lse[:, :, :32])
