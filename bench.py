@@ -31,6 +31,8 @@ finds is the --gpus it was asked for.  Every rank runs the same per-GPU workload
                    104.8 TFLOP/s = 4 / (2/78.6 + 2/157.3), the two matrix rates in series
   attention_backward  the backward (delta, dQ, dK/dV kernels) of the same shape: ms, TFLOP/s over 2.5x
                    the forward's flops, and PyTorch's SDPA backward on the same tensors
+  attention_f32_backward  the float32 backward of the headline shape (float32 matrix instructions: 157.3
+                   TFLOP/s peak; five products counted, seven executed) beside PyTorch's float32 SDPA backward
   attention_causal the same shape under the causal mask, forward and backward (half the products count)
   config5_strong_scaling  configs[4] as BASELINE states it: ONE bf16 B=8 H=32 N=16384 d=128 problem whose
                    256 (batch, head) problems are split over the ranks (sharding.head_range), aggregate
@@ -648,6 +650,9 @@ def main():
         result["power_context"] = power_context(mfa, B, H, N, d, dtype, scale)
         result["attention_f32"] = bench_attention_f32(mfa)
         result["attention_backward"] = bench_backward(mfa, B, H, N, d, dtype, scale)
+        f32b = bench_backward(mfa, B, H, N, d, torch.float32, scale)
+        f32b["frac_f32_mfma_peak_algorithmic"] = round(f32b["TFLOP/s_algorithmic"] / 157.3, 3)
+        result["attention_f32_backward"] = f32b
         result["attention_causal"] = bench_causal(mfa, B, H, N, d, dtype, scale)
         result["softmax_sweep"] = bench_softmax_sweep(mfa)
         result["softmax_1024"] = bench_softmax_1024(mfa)

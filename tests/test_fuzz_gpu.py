@@ -80,6 +80,21 @@ def test_fuzz_backward(mfa, case):
         assert np.abs(g.float().cpu().numpy() - r).max() <= 2e-2 * max(np.abs(r).max(), 1e-2)
 
 
+@pytest.mark.parametrize("case", _cases(19, 20, [1, 3, 16, 20, 40, 63, 64, 65, 99, 128, 130, 200, 256]))
+def test_fuzz_backward_f32(mfa, case):
+    """float32 backward (any head dim up to 256): 2e-5 of the largest gradient against the float64 oracle."""
+    B, H, N, d, causal, _, seed = case
+    scale = d ** -0.5
+    torch.manual_seed(seed)
+    q, k, v, do = (torch.randn(B, H, N, d) for _ in range(4))
+    qd, kd, vd, dod = (x.cuda() for x in (q, k, v, do))
+    out, lse = mfa.flash_attn_fwd(qd, kd, vd, scale=scale, return_lse=True, causal=causal)
+    got = mfa.flash_attn_bwd(dod, qd, kd, vd, out, lse, scale=scale, causal=causal)
+    ref = ref_cpu.attention_bwd_bhnd(q.numpy(), k.numpy(), v.numpy(), do.numpy(), scale=scale, causal=causal)
+    for g, r in zip(got, ref):
+        assert np.abs(g.cpu().numpy() - r).max() <= 2e-5 * max(np.abs(r).max(), 1.0)
+
+
 @pytest.mark.parametrize("case", _cases(14, 12, [1, 7, 64, 65, 128, 300]))
 def test_fuzz_my_attention_2d(mfa, case):
     _, _, N, d, _, _, seed = case

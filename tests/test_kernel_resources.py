@@ -127,3 +127,24 @@ def test_wide_head_kernels_register_budgets():
                 for a, z in mfma_loops:
                     assert not any("scratch_" in ln for ln in lines[a:z]), (m.group(1), a, z)
     assert seen >= 8 + 24, f"only {seen} builds found"
+
+
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="needs hipcc")
+def test_float32_backward_register_budgets():
+    """The float32 backward keeps its owned fragments and its accumulators in registers for the whole
+    walk over the other side: no build may spill, the builds up to head dim 128 must leave room for
+    two workgroups per CU (256 registers), and the double-buffered blocks of the 256-column build
+    must fit the CU's LDS."""
+    haz = _load("check_mfma_hazards", os.path.join(ROOT, "tools", "check_mfma_hazards.py"))
+    build = _load("myfa_build", os.path.join(ROOT, "flash-attention_amd", "build.py"))
+    src = "attn_bwd_f32.hip"
+    asm = haz.compile_to_asm(os.path.join(build.CSRC, src), build.PER_SOURCE_FLAGS.get(src, []))
+    res = {k: v for k, v in kernel_resources(asm).items() if "attn_bwd_f32_kernel" in k and "vgpr_count" in v}
+    for name, r in res.items():
+        m = re.search(r"attn_bwd_f32_kernelILi(\d+)E", name)
+        assert m, name
+        dpad = int(m.group(1))
+        assert r["vgpr_spill_count"] == 0 and r["sgpr_spill_count"] == 0, (name, r)
+        assert r["vgpr_count"] <= (256 if dpad <= 128 else 512), (name, r)
+        assert 4 * (4 * 16 * (dpad + 4) + 64) <= 160 * 1024
+    assert len(res) == 4 * 8, f"{len(res)} builds of the kernel found"
