@@ -30,6 +30,8 @@
 //
 // LDS rows are padded by 4 floats: the 16 lanes of one float4 read then cover all 64 banks once,
 // and so do the 64 lanes of one scalar read of the second kind (rows 4 g + r, 16 columns each).
+#include <algorithm>
+
 #include "myfa_common.h"
 
 namespace myfa {
@@ -292,9 +294,19 @@ int attn_bwd_f32(const float* q, const float* k, const float* v, const float* o,
                  float* dq, float* dk, float* dv, float* delta, int64_t heads, int64_t N, int64_t d,
                  float scale, bool causal, hipStream_t s) {
     if (d > 256) return fail(MYFA_E_UNSUPPORTED, "attention backward (float32): head dim %lld > 256", (long long)d);
-    if (heads > 65528 || N * d >= (1LL << 31))
-        return fail(MYFA_E_UNSUPPORTED, "attention backward (float32): heads=%lld or N*d=%lld per head beyond the kernel's limits",
-                    (long long)heads, (long long)(N * d));
+    if (N * d >= (1LL << 31))
+        return fail(MYFA_E_UNSUPPORTED, "attention backward (float32): N*d=%lld per head beyond the kernel's limit of 2^31", (long long)(N * d));
+    // heads ride on the grid's y extent (rounded up to a multiple of 8): more go in successive launches
+    constexpr int64_t kMaxHeads = 65528;
+    if (heads > kMaxHeads) {
+        for (int64_t h0 = 0; h0 < heads; h0 += kMaxHeads) {
+            const int64_t off = h0 * N * d;
+            const int rc = attn_bwd_f32(q + off, k + off, v + off, o + off, lse + h0 * N, dout + off, dq + off, dk + off, dv + off,
+                                        delta + h0 * N, std::min(kMaxHeads, heads - h0), N, d, scale, causal, s);
+            if (rc != MYFA_OK) return rc;
+        }
+        return MYFA_OK;
+    }
     if (d <= 32)  return launch_f32_flags<32>(q, k, v, o, lse, dout, dq, dk, dv, delta, heads, N, d, scale, causal, s);
     if (d <= 64)  return launch_f32_flags<64>(q, k, v, o, lse, dout, dq, dk, dv, delta, heads, N, d, scale, causal, s);
     if (d <= 128) return launch_f32_flags<128>(q, k, v, o, lse, dout, dq, dk, dv, delta, heads, N, d, scale, causal, s);

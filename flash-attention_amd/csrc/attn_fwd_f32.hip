@@ -41,6 +41,8 @@
 // its un-normalised partial (O, m, l) and attn_f32_merge_kernel combines them, so that the
 // reference's largest test shape (1024 x 64, one head: 64 query groups) runs on every CU instead
 // of 64 of them with four waves sharing each matrix pipe.
+#include <algorithm>
+
 #include "myfa_common.h"
 #include "tuning.h"
 
@@ -440,8 +442,19 @@ int attn_fwd_f32(const float* q, const float* k, const float* v, float* o, float
                  int64_t heads, int64_t N, int64_t d, int64_t k_key_stride, int64_t k_d_stride,
                  float scale, bool causal, hipStream_t s, float* ws, size_t ws_bytes) {
     if (d > 512) return fail(MYFA_E_UNSUPPORTED, "attention (f32): head dim %lld > 512", (long long)d);
-    if (N * d >= (1LL << 31) || heads > 65535)
-        return fail(MYFA_E_UNSUPPORTED, "attention (f32): N*d=%lld per head or heads=%lld beyond the kernel's limits", (long long)(N * d), (long long)heads);
+    if (N * d >= (1LL << 31))
+        return fail(MYFA_E_UNSUPPORTED, "attention (f32): N*d=%lld per head beyond the kernel's limit of 2^31", (long long)(N * d));
+    // heads ride on the grid's y extent: more than it holds go in successive launches on the stream
+    constexpr int64_t kMaxHeads = 65535;
+    if (heads > kMaxHeads) {
+        for (int64_t h0 = 0; h0 < heads; h0 += kMaxHeads) {
+            const int64_t off = h0 * N * d;
+            const int rc = attn_fwd_f32(q + off, k + off, v + off, o + off, lse ? lse + h0 * N : nullptr, std::min(kMaxHeads, heads - h0),
+                                        N, d, k_key_stride, k_d_stride, scale, causal, s, ws, ws_bytes);
+            if (rc != MYFA_OK) return rc;
+        }
+        return MYFA_OK;
+    }
     // (with d == 1 or N == 1 the two layouts are the same bytes)
     const bool rowmajor = (k_key_stride == d && k_d_stride == 1) || d == 1 || N == 1;
     const bool kt = !rowmajor;

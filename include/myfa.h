@@ -183,7 +183,7 @@ int myfa_attn_fwd_f32_ws(const float* q, const float* k_t, const float* v, float
  * MYFA_F16 / MYFA_BF16 run on MFMA and require d a multiple of 8 in 8..256 (64 and 128 are the fast
  * builds; the others run on the next build up -- 64, 128 or 256 columns -- with the missing columns
  * read as zeros), 16-byte aligned tensors and scale > 0; MYFA_F32 accepts
- * 1 <= d <= 512, B*H <= 65535 and N*d < 2^31 (myfa_attn_fwd_f32 has the same d and N*d limits;
+ * 1 <= d <= 512 and N*d < 2^31 (myfa_attn_fwd_f32 has the same limits;
  * the reference's my_attention has none, but its test shapes end at N = 1025, d = 99).  Outside
  * these limits the call returns MYFA_E_UNSUPPORTED.
  * `o` with and without `lse` agree to the rounding of the element type, not bit for bit: without
@@ -224,7 +224,7 @@ const char* myfa_attn_fwd_bhnd_kernel(int64_t d, int dtype, int flags);
 /*
  * Backward of myfa_attn_fwd_bhnd_ex for MYFA_F16 / MYFA_BF16, d in {64, 128, 192, 256}
  * (192 and 256: four-wave workgroups on 32-row tiles, dK and dV in separate launches), and for
- * MYFA_F32 with any d up to 256 (float32 matrix instructions, float32 throughout; B*H <= 65528 and
+ * MYFA_F32 with any d up to 256 (float32 matrix instructions, float32 throughout;
  * N*d < 2^31 as in the float32 forward):
  * given the forward's inputs, its output `o`, its row log-sum-exp `lse` and the
  * gradient `dout` of the output, writes dq, dk, dv (same shape and dtype as q, k, v).

@@ -311,6 +311,23 @@ def test_autograd_function_f32(mfa):
         assert float((a.double() - r).abs().max()) <= F32_BWD_TOL * max(float(r.abs().max()), 1.0)
 
 
+def test_f32_more_heads_than_a_grid_holds(mfa):
+    """B*H above 65535 (the y extent of a launch grid): the float32 forward and backward go in
+    successive launches; checked on heads of both launches against PyTorch's float64 attention."""
+    torch.manual_seed(8)
+    B, H, N, d = 3, 22000, 20, 8            # 66000 heads
+    q, k, v = (torch.randn(B, H, N, d, device="cuda", requires_grad=True) for _ in range(3))
+    do = torch.randn(B, H, N, d, device="cuda")
+    out = mfa.flash_attn_func(q, k, v, scale=d ** -0.5)
+    got = torch.autograd.grad(out, (q, k, v), do)
+    qd, kd, vd = (x.detach().double().requires_grad_(True) for x in (q, k, v))
+    ref_out = torch.nn.functional.scaled_dot_product_attention(qd, kd, vd, scale=d ** -0.5)
+    ref = torch.autograd.grad(ref_out, (qd, kd, vd), do.double())
+    assert float((out.double() - ref_out).abs().max()) <= 1e-5
+    for a, r in zip(got, ref):
+        assert float((a.double() - r).abs().max()) <= F32_BWD_TOL * max(float(r.abs().max()), 1.0)
+
+
 def test_bwd_into_f32(mfa):
     """The entry point without a workspace argument serves float32 as well, bit for bit."""
     torch.manual_seed(6)
