@@ -5,8 +5,8 @@
 
 cases: softmax32768, softmax8192, cols8192 (softmax over dim 0 of [8192, 8192]: the streamed column
 kernel), cols16384, config3 (f16 B8 H16 N1024 d64), wide256 (bf16 B4 H16 N4096 d256), causal
-(headline shape under the causal mask), bwd (backward of the headline shape), scale1 (headline shape,
-unscaled logits).  Prints the algorithmic bytes or flops of one launch.
+(headline shape under the causal mask), bwd (backward of the headline shape), bwdf32 / bwdf32causal (its
+float32 backward), scale1 (headline shape, unscaled logits).  Prints the algorithmic bytes or flops of one launch.
 """
 import os
 import sys
@@ -46,6 +46,14 @@ def main():
         out, lse = mfa.flash_attn_fwd(q, k, v, scale=d ** -0.5, return_lse=True)
         fn = lambda: mfa.flash_attn_bwd(do, q, k, v, out, lse, scale=d ** -0.5)  # noqa: E731
         note = f"algorithmic_flops {10 * B * H * N * N * d} algorithmic_bytes {8 * B * H * N * d * 2}"
+    elif case in ("bwdf32", "bwdf32causal"):
+        B, H, N, d = 4, 32, 4096, 128
+        causal = case.endswith("causal")
+        q, k, v, do = (torch.randn(B, H, N, d, device=dev) for _ in range(4))
+        out, lse = mfa.flash_attn_fwd(q, k, v, scale=d ** -0.5, return_lse=True, causal=causal)
+        fn = lambda: mfa.flash_attn_bwd(do, q, k, v, out, lse, scale=d ** -0.5, causal=causal)  # noqa: E731
+        n = min(n, 3)
+        note = f"algorithmic_flops {10 * B * H * N * N * d * (0.5 if causal else 1.0):.0f} algorithmic_bytes {8 * B * H * N * d * 4}"
     else:
         raise SystemExit(f"unknown case {case}")
     for _ in range(n):
