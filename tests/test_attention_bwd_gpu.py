@@ -323,7 +323,7 @@ def test_f32_more_heads_than_a_grid_holds(mfa):
     qd, kd, vd = (x.detach().double().requires_grad_(True) for x in (q, k, v))
     ref_out = torch.nn.functional.scaled_dot_product_attention(qd, kd, vd, scale=d ** -0.5)
     ref = torch.autograd.grad(ref_out, (qd, kd, vd), do.double())
-    assert float((out.double() - ref_out).abs().max()) <= 1e-5
+    assert float((out.detach().double() - ref_out.detach()).abs().max()) <= 1e-5
     for a, r in zip(got, ref):
         assert float((a.double() - r).abs().max()) <= F32_BWD_TOL * max(float(r.abs().max()), 1.0)
 

@@ -10,6 +10,11 @@ CASES = [((8192, 8192), 0, torch.float32), ((16384, 16384), 0, torch.float32), (
          ((32, 1024, 4096), 1, torch.float32), ((256, 64, 64, 64), 1, torch.float32), ((4096, 64, 512), 1, torch.float32),
          ((8192, 8192), 0, torch.bfloat16), ((64, 128, 16384), 1, torch.bfloat16)]
 
+# extra cases on the command line: 8192x1024:0:bfloat16
+_DT = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float16": torch.float16}
+if len(sys.argv) > 1:
+    CASES = [(tuple(int(n) for n in a.split(":")[0].split("x")), int(a.split(":")[1]), _DT[a.split(":")[2]]) for a in sys.argv[1:]]
+
 
 def med(fn, it=20):
     for _ in range(3):
