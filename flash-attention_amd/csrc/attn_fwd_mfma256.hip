@@ -96,7 +96,7 @@ attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, co
         const int ch = 4 * (within >> 5) + ((within & 3) ^ ((row >> 2) & 3));
         goff[i] = ch * 8 < gd ? (row * gd + ch * 8) * 2 : kPastEndW;
     }
-    const int tile_stride = TR * gd * 2;          // bytes of a tile in memory
+    [[maybe_unused]] const int tile_stride = TR * gd * 2;          // bytes of a tile in memory
     // piece p of a fetch (p < 2 LPT): even p this wave's piece p/2 of K tile `kt` into K buffer `kbuf`,
     // odd p that of V tile `vt` into V buffer `vbuf`.  (The host pass of hipcc silently drops a
     // kernel whose body names this builtin.)
@@ -127,15 +127,15 @@ attn_fwd_mfma_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, co
     // follows its last read, and read only behind the barrier that follows the fetching waves' wait.
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)lds;
     auto k_frag = [&]([[maybe_unused]] unsigned a0, [[maybe_unused]] unsigned a1, auto ks_) __attribute__((always_inline)) -> s16x8 {
-        constexpr int ks = decltype(ks_)::value;
-        s16x8 a;
+        [[maybe_unused]] constexpr int ks = decltype(ks_)::value;
+        s16x8 a = {};          // (the host pass sees no asm; the device pass overwrites it)
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a) : "v"((ks & 1) ? a1 : a0), "n"(512 * (ks >> 1)));
 #endif
         return a;
     };
     auto v_frag = [&]([[maybe_unused]] unsigned a0, [[maybe_unused]] unsigned a1, auto i_) __attribute__((always_inline)) -> s16x8 {
-        constexpr int i = decltype(i_)::value, st = i / DB, db = i % DB;       // 16 keys x 32 columns
+        [[maybe_unused]] constexpr int i = decltype(i_)::value, st = i / DB, db = i % DB;       // 16 keys x 32 columns
         s16x4 lo, hi;
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "n"(16 * D * 2 * st + 512 * db));
