@@ -66,6 +66,33 @@ struct FragBase {
     __device__ __forceinline__ s16x8 row(const char* tile, int ks) const {
         return *reinterpret_cast<const s16x8*>(tile + rbase[ks & 1] + 512 * (ks >> 1));
     }
+    // The same two reads as instructions the compiler does not see as LDS reads: hipcc makes an LDS
+    // read that follows an LDS-DMA fetch wait for ALL fetches in flight (it cannot tell the buffers
+    // apart), and the kernels below keep the fetches of two tiles in flight.  `tile` is the buffer's
+    // LDS byte address; the caller waits for the fragment with frag_wait<younger requests>() before
+    // its first use.  What orders these reads against the fetches: a buffer is fetched into only
+    // behind the barrier that follows its last read, and read only behind the barrier that follows
+    // the fetching waves' counted s_waitcnt vmcnt.
+    template <int KSTEP>
+    __device__ __forceinline__ s16x8 row_a([[maybe_unused]] unsigned tile) const {
+        s16x8 a = {};
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a) : "v"(tile + rbase[KSTEP & 1]), "n"(512 * (KSTEP >> 1)));
+#endif
+        return a;
+    }
+    template <int ST, int DBLK>
+    __device__ __forceinline__ s16x8 tr_a([[maybe_unused]] unsigned tile) const {
+        s16x4 lo = {}, hi = {};
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(tile + tbase[0]), "n"(16 * D * 2 * ST + 512 * DBLK));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(tile + tbase[1]), "n"(16 * D * 2 * ST + 512 * DBLK));
+#endif
+        s16x8 a;
+        a[0] = lo[0]; a[1] = lo[1]; a[2] = lo[2]; a[3] = lo[3];
+        a[4] = hi[0]; a[5] = hi[1]; a[6] = hi[2]; a[7] = hi[3];
+        return a;
+    }
     __device__ __forceinline__ s16x8 tr(const char* tile, int st, int db) const {
         const int imm = 16 * D * 2 * st + 512 * db;
         const s16x4 lo = lds_read_tr(tile + tbase[0] + imm);
@@ -76,6 +103,45 @@ struct FragBase {
         return a;
     }
 };
+
+// Waits until at most N LDS requests younger than the one that produced `a` are outstanding; tied to
+// `a` so that the compiler keeps the fragment's first use behind it.
+template <int N, typename V>
+__device__ __forceinline__ void frag_wait([[maybe_unused]] V& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N));
+#endif
+}
+template <int N>
+__device__ __forceinline__ void fetch_wait() {      // at most N LDS-DMA pieces of this wave still in flight
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+#endif
+}
+// Behind the last of a run of asm-form MFMAs (Mma::acc_v / acc_a), in front of the first vector
+// instruction that touches their result: the result latency of 8 passes, which the compiler does not
+// know about.
+// Tied to the accumulators so that the compiler keeps their readers behind it.
+template <typename V>
+__device__ __forceinline__ void tie_v([[maybe_unused]] V& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(c));
+#endif
+}
+template <typename... V>
+__device__ __forceinline__ void mfma_drain_v(V&... c) {
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    (tie_v(c), ...);
+}
+template <typename V, int NACC>
+__device__ __forceinline__ void mfma_drain_a([[maybe_unused]] V (&c)[NACC]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) asm volatile("" : "+a"(c[i]));
+#endif
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(lds_void*)p; }
 
 // Per-lane source offsets of a wave's 1-KiB pieces of a 32 x D tile: piece i of wave w is image bytes
 // 1024 (w LPT + i) .. + 1023, lane L at + 16 L, so the image is produced by choosing each lane's
@@ -110,7 +176,8 @@ attn_bwd_dq_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
     constexpr int LPT = TR * (D / 8) / kThreadsW;
     static_assert(LPT * kThreadsW == TR * (D / 8), "whole 1-KiB pieces per wave");
 
-    __shared__ __attribute__((aligned(16))) char lds[6 * TILE_B];   // K0 K1 K2 V0 V1 V2
+    constexpr int NBUF = 4;                        // tiles t .. t + 3: two tiles' fetches in flight behind the one in use
+    __shared__ __attribute__((aligned(16))) char lds[2 * NBUF * TILE_B];   // K0..K3 V0..V3
 
     int lid;
     {
@@ -157,57 +224,65 @@ attn_bwd_dq_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
             __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (lds_void*)(lds + buf * TILE_B + 1024 * (wave * LPT + p / 2)),
                                                      16, goff[p / 2], tile * TILE_B, 0, 0);
         else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_void*)(lds + (3 + buf) * TILE_B + 1024 * (wave * LPT + p / 2)),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (lds_void*)(lds + (NBUF + buf) * TILE_B + 1024 * (wave * LPT + p / 2)),
                                                      16, goff[p / 2], tile * TILE_B, 0, 0);
 #endif
     };
 
     const int T_all = (N + TR - 1) / TR;
     const int ntiles = CAUSAL ? min(T_all, (q0 + BQ) / TR) : T_all;
+    // tiles 0 and 1 complete, tile 2 in flight (a tile past the end reads zeros without touching memory)
 #pragma unroll
     for (int p = 0; p < 2 * LPT; ++p) fetch_piece(0, 0, p);
 #pragma unroll
     for (int p = 0; p < 2 * LPT; ++p) fetch_piece(1 < ntiles ? 1 : T_all, 1, p);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int p = 0; p < 2 * LPT; ++p) fetch_piece(2 < ntiles ? 2 : T_all, 2, p);
+    fetch_wait<2 * LPT>();
     __syncthreads();
-    int cur = 0, nxt = 1, fre = 2;                 // buffers of tile t, t + 1, t + 2
 
     const FragBase<D> fb(lane);
+    const unsigned lds0 = lds_addr(lds);
     constexpr int FW = 4;                          // LDS fragments requested ahead of the MFMA stream
-    // the fetch of tile t + 2 is spread over the last FW steps of tile t, behind its last fragment request
+    // the fetch of tile t + 3 is spread over the last FW steps of tile t, behind its last fragment request
     constexpr int S0 = 2 * DB - FW, PPS = (2 * LPT + FW - 1) / FW;
 
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * TR;
-        const char* Kb = lds + cur * TILE_B;
-        const char* Vb = lds + (3 + cur) * TILE_B;
+        const int cur = t & (NBUF - 1), fre = (t + 3) & (NBUF - 1);
 
         f32x16 s, dp;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
         {
+            const unsigned Ka = lds0 + cur * TILE_B, Va = lds0 + (NBUF + cur) * TILE_B;
             s16x8 win[FW];
-#pragma unroll
-            for (int i = 0; i < FW; ++i) win[i] = fb.row(i / KS ? Vb : Kb, i % KS);
-#pragma unroll
-            for (int i = 0; i < 2 * KS; ++i) {
-                const s16x8 a = win[i % FW];
-                if (i / KS) dp = M::run(a, dof[i % KS], dp);
-                else s = M::run(a, qf[i % KS], s);
-                if (i + FW < 2 * KS) win[i % FW] = fb.row((i + FW) / KS ? Vb : Kb, (i + FW) % KS);
+            static_for<FW>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                win[i] = fb.template row_a<i % KS>(i / KS ? Va : Ka);
+            });
+            static_for<2 * KS>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                s16x8 a = win[i % FW];
+                frag_wait<(2 * KS - 1 - i < FW - 1 ? 2 * KS - 1 - i : FW - 1)>(a);
+                // (VGPR-form MFMAs: vector instructions consume S and dP, see Mma::acc_v)
+                if constexpr (i == 0) M::first_v(a, qf[0], s);
+                else if constexpr (i < KS) M::acc_v(a, qf[i], s);
+                else if constexpr (i == KS) M::first_v(a, dof[0], dp);
+                else M::acc_v(a, dof[i - KS], dp);
+                if constexpr (i + FW < 2 * KS) win[i % FW] = fb.template row_a<(i + FW) % KS>((i + FW) / KS ? Va : Ka);
                 // P needs S only: its scale-subtract and exp2 run, two elements a step, in the shadow of
                 // the MFMAs of dP^T (from the third on: S's last MFMA has to land first)
-                if (i >= KS + 2) {
+                if constexpr (i >= KS + 2) {
 #pragma unroll
                     for (int e = 2 * (i - KS - 2); e < 2 * (i - KS - 2) + 2; ++e)
                         if (e < 16) s[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], sl2, -lse2));
                 }
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            });
         }
         static_assert(2 * (KS - 2) >= 16, "every element of P is formed under the dP stream");
         // accumulator register i is key kv0 + (i & 3) + 8 (i >> 2) + 4 h of the lane's query
         const bool edge = kv0 + TR > N || (CAUSAL && kv0 + TR - 1 > q0 + 32 * wave);
+        mfma_drain_v(s, dp);                       // dP's last MFMA has just been issued
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] *= dp[i] + ndelta;
         if (edge) {
@@ -223,37 +298,40 @@ attn_bwd_dq_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
 #pragma unroll
             for (int j = 0; j < 8; ++j) sb[st][j] = (T)s[8 * st + j];
         {
+            const unsigned Ka = lds0 + cur * TILE_B;
             s16x8 win[FW];
-#pragma unroll
-            for (int i = 0; i < FW; ++i) win[i] = fb.tr(Kb, i / DB, i % DB);
-#pragma unroll
-            for (int i = 0; i < 2 * DB; ++i) {
-                const s16x8 a = win[i % FW];
-                dq[i % DB] = M::run(a, sb[i / DB], dq[i % DB]);
-                if (i + FW < 2 * DB) win[i % FW] = fb.tr(Kb, (i + FW) / DB, (i + FW) % DB);
-                // tile t + 2 into the buffer tile t - 1 was read from (everybody left it at the last
+            static_for<FW>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                win[i] = fb.template tr_a<i / DB, i % DB>(Ka);
+            });
+            static_for<2 * DB>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                s16x8 a = win[i % FW];
+                frag_wait<2 * (2 * DB - 1 - i < FW - 1 ? 2 * DB - 1 - i : FW - 1)>(a);     // (two reads a fragment)
+                M::acc_a(a, sb[i / DB], dq[i % DB]);       // (pinned to accumulator registers: only MFMAs touch dQ in the loop)
+                if constexpr (i + FW < 2 * DB) win[i % FW] = fb.template tr_a<(i + FW) / DB, (i + FW) % DB>(Ka);
+                // tile t + 3 into the buffer tile t - 1 was read from (everybody left it at the last
                 // barrier; a tile past the end reads zeros).  The wait in front confirms this wave's
-                // pieces of tile t + 1, issued a tile ago.
-                if (i == S0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (i >= S0) {
+                // pieces of tile t + 1, issued two tiles ago; those of tile t + 2 stay in flight.
+                if constexpr (i == S0) fetch_wait<2 * LPT>();
+                if constexpr (i >= S0) {
 #pragma unroll
                     for (int e = 0; e < PPS; ++e) {
                         const int p = PPS * (i - S0) + e;
-                        if (p < 2 * LPT) fetch_piece(t + 2 < ntiles ? t + 2 : T_all, fre, p);
+                        if (p < 2 * LPT) fetch_piece(t + 3 < ntiles ? t + 3 : T_all, fre, p);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            });
         }
         // tile t + 1 complete (all waves' pieces), tile t released; the bare barrier, not
-        // __syncthreads(), which would first wait for the loads issued a moment ago
+        // __syncthreads(), which would first wait for the loads in flight
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const int was = cur;
-        cur = nxt; nxt = fre; fre = was;
     }
 
+    mfma_drain_a(dq);
     if (qrow < N) {
         T* row = dQg + hoff + (size_t)qrow * D;
 #pragma unroll
@@ -288,10 +366,12 @@ attn_bwd_dkv_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, con
     constexpr int LPT = TR * (D / 8) / kThreadsW;
     static_assert(LPT * kThreadsW == TR * (D / 8), "whole 1-KiB pieces per wave");
 
-    // Q0 Q1 Q2 dO0 dO1 dO2, then per buffer 64 floats of lse2 and 64 of -delta (a wave-wide 4-byte
-    // fetch writes 64 floats: the tile's 32 rows and the 32 behind them, which nobody reads)
-    __shared__ __attribute__((aligned(16))) char lds[6 * TILE_B + 3 * 2 * 64 * 4];
-    float* stat = reinterpret_cast<float*>(lds + 6 * TILE_B);
+    // Q0..Q3 dO0..dO3 (tiles j .. j + 3: two tiles' fetches in flight behind the one in use), then per
+    // buffer 64 floats of lse2 and 64 of -delta (a wave-wide 4-byte fetch writes 64 floats: the tile's
+    // 32 rows and the 32 behind them, which nobody reads)
+    constexpr int NBUF = 4;
+    __shared__ __attribute__((aligned(16))) char lds[2 * NBUF * TILE_B + NBUF * 2 * 64 * 4];
+    [[maybe_unused]] float* stat = reinterpret_cast<float*>(lds + 2 * NBUF * TILE_B);
 
     int lid;
     {
@@ -324,16 +404,18 @@ attn_bwd_dkv_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, con
     int goff[LPT];
     piece_offsets<D, LPT>(wave, lane, goff);
     // piece p of a tile's fetch: even p < 2 LPT this wave's KiB piece p/2 of Q, odd p that of dO;
-    // piece 2 LPT the row statistics (wave 0)
+    // piece 2 LPT the row statistics -- by every wave (the same 256 bytes to the same place), so that
+    // all waves have the same number of fetches in flight and one counted wait serves them
+    constexpr int NPIECE = 2 * LPT + (DV ? 1 : 2);      // fetch instructions per wave and tile
     auto fetch_piece = [&](int tile, int buf, int p) __attribute__((always_inline)) {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (p < 2 * LPT && (p & 1) == 0) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (lds_void*)(lds + buf * TILE_B + 1024 * (wave * LPT + p / 2)),
                                                      16, goff[p / 2], tile * TILE_B, 0, 0);
         } else if (p < 2 * LPT) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ors, (lds_void*)(lds + (3 + buf) * TILE_B + 1024 * (wave * LPT + p / 2)),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ors, (lds_void*)(lds + (NBUF + buf) * TILE_B + 1024 * (wave * LPT + p / 2)),
                                                      16, goff[p / 2], tile * TILE_B, 0, 0);
-        } else if (wave == 0) {
+        } else {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(lrs, (lds_void*)(stat + buf * 128), 4, lane * 4, tile * TR * 4, 0, 0);
             if constexpr (!DV)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void*)(stat + buf * 128 + 64), 4, lane * 4, tile * TR * 4, 0, 0);
@@ -349,59 +431,81 @@ attn_bwd_dkv_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, con
 
     const int T_all = (N + TR - 1) / TR;
     const int t0 = CAUSAL ? k0 / TR : 0;           // causal: queries before the block's first key see none of it
+    // tiles t0 and t0 + 1 complete, tile t0 + 2 in flight (a tile past the end reads zeros)
 #pragma unroll
     for (int p = 0; p <= 2 * LPT; ++p) fetch_piece(t0, 0, p);
 #pragma unroll
     for (int p = 0; p <= 2 * LPT; ++p) fetch_piece(t0 + 1 < T_all ? t0 + 1 : T_all, 1, p);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int p = 0; p <= 2 * LPT; ++p) fetch_piece(t0 + 2 < T_all ? t0 + 2 : T_all, 2, p);
+    fetch_wait<NPIECE>();
     __syncthreads();
-    int cur = 0, nxt = 1, fre = 2;                 // buffers of tile j, j + 1, j + 2
 
     const FragBase<D> fb(lane);
+    const unsigned lds0 = lds_addr(lds);
     constexpr int FW = 4;
     constexpr int NA = DV ? KS : 2 * KS;           // MFMAs of the tile's first stream
     constexpr int S0 = 2 * DB - FW, PPS = (2 * LPT + 1 + FW - 1) / FW;
 
     for (int j = t0; j < T_all; ++j) {
         const int qt0 = j * TR;
-        const char* Qb = lds + cur * TILE_B;
-        const char* dOb = lds + (3 + cur) * TILE_B;
-        const float* lse2b = stat + cur * 128;
+        const int cur = (j - t0) & (NBUF - 1), fre = (j - t0 + 3) & (NBUF - 1);
+        const unsigned Qa = lds0 + cur * TILE_B, dOa = lds0 + (NBUF + cur) * TILE_B;
 
         // accumulator register i is query qt0 + (i & 3) + 8 (i >> 2) + 4 h: the rows' lse2 come as four
-        // broadcast float4 reads, and four more start the dP accumulators at -delta
+        // broadcast float4 reads, and four more start the dP accumulators at -delta.  (Asm reads like the
+        // fragments': a read the compiler knows as one would wait for the fetches in flight.)
         f32x16 s, dp;
         f32x4 l4[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            l4[g] = *reinterpret_cast<const f32x4*>(lse2b + 8 * g + 4 * h);
-            if constexpr (!DV) {
-                const f32x4 nd = *reinterpret_cast<const f32x4*>(lse2b + 64 + 8 * g + 4 * h);
-                dp[4 * g] = nd[0]; dp[4 * g + 1] = nd[1]; dp[4 * g + 2] = nd[2]; dp[4 * g + 3] = nd[3];
-            }
+        [[maybe_unused]] f32x4 nd4[4];
+        {
+            [[maybe_unused]] const unsigned sa = lds0 + 2 * NBUF * TILE_B + cur * 512 + 16 * h;
+#if defined(__HIP_DEVICE_COMPILE__)
+            static_for<4>([&](auto gc) __attribute__((always_inline)) {
+                constexpr int g = decltype(gc)::value;
+                [[maybe_unused]] auto& nd = nd4;           // (captured here: inside the discarded branch clang does not)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(l4[g]) : "v"(sa), "n"(32 * g));
+                if constexpr (!DV) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(nd[g]) : "v"(sa), "n"(256 + 32 * g));
+            });
+#endif
         }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = 0.f;
         {
             s16x8 win[FW];
+            static_for<FW>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                win[i] = fb.template row_a<i % KS>(i / KS ? dOa : Qa);
+            });
+            // the statistics are older than the FW fragment requests behind them
+#if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (DV) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(l4[0]), "+v"(l4[1]), "+v"(l4[2]), "+v"(l4[3]) : "n"(FW));
+            else asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(l4[0]), "+v"(l4[1]), "+v"(l4[2]), "+v"(l4[3]),
+                              "+v"(nd4[0]), "+v"(nd4[1]), "+v"(nd4[2]), "+v"(nd4[3]) : "n"(FW));
+#endif
+            if constexpr (!DV) {
 #pragma unroll
-            for (int i = 0; i < FW; ++i) win[i] = fb.row(i / KS ? dOb : Qb, i % KS);
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const s16x8 a = win[i % FW];
-                if (i / KS) { if constexpr (!DV) dp = M::run(a, vf[i % KS], dp); }
-                else s = M::run(a, kf[i % KS], s);
-                if (i + FW < NA) win[i % FW] = fb.row((i + FW) / KS ? dOb : Qb, (i + FW) % KS);
+                for (int g = 0; g < 4; ++g) { dp[4 * g] = nd4[g][0]; dp[4 * g + 1] = nd4[g][1]; dp[4 * g + 2] = nd4[g][2]; dp[4 * g + 3] = nd4[g][3]; }
+            }
+            static_for<NA>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                s16x8 a = win[i % FW];
+                frag_wait<(NA - 1 - i < FW - 1 ? NA - 1 - i : FW - 1)>(a);
+                // (VGPR-form MFMAs: vector instructions consume S and dP, see Mma::acc_v)
+                if constexpr (i == 0) M::first_v(a, kf[0], s);
+                else if constexpr (i < KS) M::acc_v(a, kf[i], s);
+                else if constexpr (!DV) M::acc_v(a, vf[i - KS], dp);
+                if constexpr (i + FW < NA) win[i % FW] = fb.template row_a<(i + FW) % KS>((i + FW) / KS ? dOa : Qa);
                 // dK pass: P needs S only, so it is formed in the shadow of the MFMAs of dP (from the
                 // third on: S's last MFMA has to land first), two elements a step
-                if (!DV && i >= KS + 2) {
+                if constexpr (!DV && i >= KS + 2) {
 #pragma unroll
                     for (int e = 2 * (i - KS - 2); e < 2 * (i - KS - 2) + 2; ++e)
                         if (e < 16) s[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], sl2, -l4[e >> 2][e & 3]));
                 }
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            });
         }
+        if constexpr (DV) mfma_drain_v(s);         // the stream's last MFMA has just been issued
+        else mfma_drain_v(s, dp);
         static_assert(2 * (KS - 2) >= 16, "every element of P is formed under the dP stream");
         // pairs (query, key) outside the problem or above the diagonal: element c = 8 (i >> 2) + (i & 3)
         // of this lane is masked iff c >= c_hi or c < c_lo
@@ -426,35 +530,38 @@ attn_bwd_dkv_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, con
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) pb[st][jj] = (T)s[8 * st + jj];
         {
-            const char* tile = DV ? dOb : Qb;
+            const unsigned tile = DV ? dOa : Qa;
             s16x8 win[FW];
-#pragma unroll
-            for (int i = 0; i < FW; ++i) win[i] = fb.tr(tile, i / DB, i % DB);
-#pragma unroll
-            for (int i = 0; i < 2 * DB; ++i) {
-                const s16x8 a = win[i % FW];
-                acc[i % DB] = M::run(a, pb[i / DB], acc[i % DB]);
-                if (i + FW < 2 * DB) win[i % FW] = fb.tr(tile, (i + FW) / DB, (i + FW) % DB);
-                // tile j + 2 into the buffer tile j - 1 was read from, behind the tile's last fragment
-                // request; the wait in front confirms this wave's pieces of tile j + 1
-                if (i == S0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (i >= S0) {
+            static_for<FW>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                win[i] = fb.template tr_a<i / DB, i % DB>(tile);
+            });
+            static_for<2 * DB>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                s16x8 a = win[i % FW];
+                frag_wait<2 * (2 * DB - 1 - i < FW - 1 ? 2 * DB - 1 - i : FW - 1)>(a);     // (two reads a fragment)
+                M::acc_a(a, pb[i / DB], acc[i % DB]);      // (pinned to accumulator registers: only MFMAs touch it in the loop)
+                if constexpr (i + FW < 2 * DB) win[i % FW] = fb.template tr_a<(i + FW) / DB, (i + FW) % DB>(tile);
+                // tile j + 3 into the buffer tile j - 1 was read from, behind the tile's last fragment
+                // request; the wait in front confirms this wave's pieces of tile j + 1 (those of
+                // tile j + 2 stay in flight)
+                if constexpr (i == S0) fetch_wait<NPIECE>();
+                if constexpr (i >= S0) {
 #pragma unroll
                     for (int e = 0; e < PPS; ++e) {
                         const int p = PPS * (i - S0) + e;
-                        if (p <= 2 * LPT) fetch_piece(j + 2 < T_all ? j + 2 : T_all, fre, p);
+                        if (p <= 2 * LPT) fetch_piece(j + 3 < T_all ? j + 3 : T_all, fre, p);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            });
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const int was = cur;
-        cur = nxt; nxt = fre; fre = was;
     }
 
+    mfma_drain_a(acc);
     if (krow < N) {
         T* row = OUTg + hoff + (size_t)krow * D;
         const float f = DV ? 1.0f : scale;

@@ -5,7 +5,7 @@
 
 cases: softmax32768, softmax8192, cols8192 (softmax over dim 0 of [8192, 8192]: the streamed column
 kernel), cols16384, config3 (f16 B8 H16 N1024 d64), wide256 (bf16 B4 H16 N4096 d256), causal
-(headline shape under the causal mask), bwd (backward of the headline shape), bwdf32 / bwdf32causal (its
+(headline shape under the causal mask), bwd (backward of the headline shape), bwdwide (bf16 B4 H16 N4096 d256 backward), bwdf32 / bwdf32causal (the headline shape's
 float32 backward), scale1 (headline shape, unscaled logits).  Prints the algorithmic bytes or flops of one launch.
 """
 import os
@@ -42,6 +42,12 @@ def main():
         note = f"algorithmic_flops {4 * B * H * N * N * d * (0.5 if case == 'causal' else 1.0):.0f} algorithmic_bytes {4 * B * H * N * d * 2}"
     elif case == "bwd":
         B, H, N, d = 4, 32, 4096, 128
+        q, k, v, do = (torch.randn(B, H, N, d, dtype=torch.bfloat16, device=dev) for _ in range(4))
+        out, lse = mfa.flash_attn_fwd(q, k, v, scale=d ** -0.5, return_lse=True)
+        fn = lambda: mfa.flash_attn_bwd(do, q, k, v, out, lse, scale=d ** -0.5)  # noqa: E731
+        note = f"algorithmic_flops {10 * B * H * N * N * d} algorithmic_bytes {8 * B * H * N * d * 2}"
+    elif case == "bwdwide":
+        B, H, N, d = 4, 16, 4096, 256
         q, k, v, do = (torch.randn(B, H, N, d, dtype=torch.bfloat16, device=dev) for _ in range(4))
         out, lse = mfa.flash_attn_fwd(q, k, v, scale=d ** -0.5, return_lse=True)
         fn = lambda: mfa.flash_attn_bwd(do, q, k, v, out, lse, scale=d ** -0.5)  # noqa: E731

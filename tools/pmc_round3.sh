@@ -14,6 +14,7 @@ run wide256 attn_fwd_mfma_wide
 run causal attn_fwd_
 run scale1 attn_fwd_
 run bwd attn_bwd_dq attn_bwd_dkv attn_bwd_delta
+run bwdwide attn_bwd_dq_wide attn_bwd_dkv_wide
 run bwdf32 attn_bwd_f32_kernel
 run bwdf32causal attn_bwd_f32_kernel
 exit 0
