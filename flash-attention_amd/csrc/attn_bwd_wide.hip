@@ -244,8 +244,9 @@ attn_bwd_dq_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
     const FragBase<D> fb(lane);
     const unsigned lds0 = lds_addr(lds);
     constexpr int FW = 4;                          // LDS fragments requested ahead of the MFMA stream
-    // the fetch of tile t + 3 is spread over the last FW steps of tile t, behind its last fragment request
-    constexpr int S0 = 2 * DB - FW, PPS = (2 * LPT + FW - 1) / FW;
+    // the fetch of tile t + 3 is spread over the S / dP stream of tile t
+    constexpr int FSTEP = 2 * KS / (2 * LPT);
+    static_assert(FSTEP >= 2 && 2 * 2 * LPT < 64, "a piece every FSTEP steps; the counted wait fits the counter");
 
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * TR;
@@ -266,9 +267,11 @@ attn_bwd_dq_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
                 // (VGPR-form MFMAs: vector instructions consume S and dP, see Mma::acc_v)
                 if constexpr (i == 0) M::first_v(a, qf[0], s);
                 else if constexpr (i < KS) M::acc_v(a, qf[i], s);
-                else if constexpr (i == KS) M::first_v(a, dof[0], dp);
                 else M::acc_v(a, dof[i - KS], dp);
                 if constexpr (i + FW < 2 * KS) win[i % FW] = fb.template row_a<(i + FW) % KS>((i + FW) / KS ? Va : Ka);
+                // dP^T starts from -delta (two registers a step, under the S stream), so that
+                // dS = P o (dP - delta) is one multiplication
+                if constexpr (i < 8) { dp[2 * i] = ndelta; dp[2 * i + 1] = ndelta; }
                 // P needs S only: its scale-subtract and exp2 run, two elements a step, in the shadow of
                 // the MFMAs of dP^T (from the third on: S's last MFMA has to land first)
                 if constexpr (i >= KS + 2) {
@@ -276,6 +279,10 @@ attn_bwd_dq_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
                     for (int e = 2 * (i - KS - 2); e < 2 * (i - KS - 2) + 2; ++e)
                         if (e < 16) s[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], sl2, -lse2));
                 }
+                // tile t + 3 into the buffer tile t - 1 was read from (everybody left it at the last
+                // barrier; a tile past the end reads zeros): one piece every FSTEP steps (a piece costs
+                // the wave some 40 cycles of issue: four in a row under one MFMA stall the stream)
+                if constexpr (i % FSTEP == 1 && i / FSTEP < 2 * LPT) fetch_piece(t + 3 < ntiles ? t + 3 : T_all, fre, i / FSTEP);
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
@@ -284,7 +291,7 @@ attn_bwd_dq_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
         const bool edge = kv0 + TR > N || (CAUSAL && kv0 + TR - 1 > q0 + 32 * wave);
         mfma_drain_v(s, dp);                       // dP's last MFMA has just been issued
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] *= dp[i] + ndelta;
+        for (int i = 0; i < 16; ++i) s[i] *= dp[i];
         if (edge) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -310,22 +317,13 @@ attn_bwd_dq_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, cons
                 frag_wait<2 * (2 * DB - 1 - i < FW - 1 ? 2 * DB - 1 - i : FW - 1)>(a);     // (two reads a fragment)
                 M::acc_a(a, sb[i / DB], dq[i % DB]);       // (pinned to accumulator registers: only MFMAs touch dQ in the loop)
                 if constexpr (i + FW < 2 * DB) win[i % FW] = fb.template tr_a<(i + FW) / DB, (i + FW) % DB>(Ka);
-                // tile t + 3 into the buffer tile t - 1 was read from (everybody left it at the last
-                // barrier; a tile past the end reads zeros).  The wait in front confirms this wave's
-                // pieces of tile t + 1, issued two tiles ago; those of tile t + 2 stay in flight.
-                if constexpr (i == S0) fetch_wait<2 * LPT>();
-                if constexpr (i >= S0) {
-#pragma unroll
-                    for (int e = 0; e < PPS; ++e) {
-                        const int p = PPS * (i - S0) + e;
-                        if (p < 2 * LPT) fetch_piece(t + 3 < ntiles ? t + 3 : T_all, fre, p);
-                    }
-                }
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
-        // tile t + 1 complete (all waves' pieces), tile t released; the bare barrier, not
-        // __syncthreads(), which would first wait for the loads in flight
+        // this wave's pieces of tile t + 1, issued two tiles ago, are in; those of tiles t + 2 and t + 3
+        // stay in flight.  Behind the barrier tile t + 1 is complete (all waves' pieces) and tile t
+        // released; the bare barrier, not __syncthreads(), which would first wait for the loads in flight
+        fetch_wait<2 * 2 * LPT>();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -445,7 +443,7 @@ attn_bwd_dkv_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, con
     const unsigned lds0 = lds_addr(lds);
     constexpr int FW = 4;
     constexpr int NA = DV ? KS : 2 * KS;           // MFMAs of the tile's first stream
-    constexpr int S0 = 2 * DB - FW, PPS = (2 * LPT + 1 + FW - 1) / FW;
+    static_assert((NA + 2 * DB - 2) / 3 >= 2 * LPT && 2 * NPIECE < 64, "every piece has its step; the counted wait fits the counter");
 
     for (int j = t0; j < T_all; ++j) {
         const int qt0 = j * TR;
@@ -494,6 +492,9 @@ attn_bwd_dkv_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, con
                 else if constexpr (i < KS) M::acc_v(a, kf[i], s);
                 else if constexpr (!DV) M::acc_v(a, vf[i - KS], dp);
                 if constexpr (i + FW < NA) win[i % FW] = fb.template row_a<(i + FW) % KS>((i + FW) / KS ? dOa : Qa);
+                // tile j + 3 into the buffer tile j - 1 was read from: one piece every third step of the
+                // tile's two streams (a piece costs the wave some 40 cycles of issue)
+                if constexpr (i % 3 == 1 && i / 3 <= 2 * LPT) fetch_piece(j + 3 < T_all ? j + 3 : T_all, fre, i / 3);
                 // dK pass: P needs S only, so it is formed in the shadow of the MFMAs of dP (from the
                 // third on: S's last MFMA has to land first), two elements a step
                 if constexpr (!DV && i >= KS + 2) {
@@ -542,20 +543,13 @@ attn_bwd_dkv_wide_kernel(const T* __restrict__ Qg, const T* __restrict__ Kg, con
                 frag_wait<2 * (2 * DB - 1 - i < FW - 1 ? 2 * DB - 1 - i : FW - 1)>(a);     // (two reads a fragment)
                 M::acc_a(a, pb[i / DB], acc[i % DB]);      // (pinned to accumulator registers: only MFMAs touch it in the loop)
                 if constexpr (i + FW < 2 * DB) win[i % FW] = fb.template tr_a<(i + FW) / DB, (i + FW) % DB>(tile);
-                // tile j + 3 into the buffer tile j - 1 was read from, behind the tile's last fragment
-                // request; the wait in front confirms this wave's pieces of tile j + 1 (those of
-                // tile j + 2 stay in flight)
-                if constexpr (i == S0) fetch_wait<NPIECE>();
-                if constexpr (i >= S0) {
-#pragma unroll
-                    for (int e = 0; e < PPS; ++e) {
-                        const int p = PPS * (i - S0) + e;
-                        if (p <= 2 * LPT) fetch_piece(j + 3 < T_all ? j + 3 : T_all, fre, p);
-                    }
-                }
+                if constexpr ((NA + i) % 3 == 1 && (NA + i) / 3 <= 2 * LPT) fetch_piece(j + 3 < T_all ? j + 3 : T_all, fre, (NA + i) / 3);
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
+        // this wave's pieces of tile j + 1, issued two tiles ago, are in; those of tiles j + 2 and j + 3
+        // stay in flight
+        fetch_wait<2 * NPIECE>();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
