@@ -223,7 +223,7 @@ def profiled_softmax_traffic():
                       "source": os.path.relpath(files[-1], ROOT)}
     with open(files[-1]) as fh:
         for line in fh:
-            m = re.match(r"^=== (\w+) ===", line)
+            m = re.match(r"^=== (\w+)", line)
             if m:
                 close()
                 sm = re.match(r"^softmax(\d+)$", m.group(1))
