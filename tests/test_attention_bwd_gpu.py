@@ -288,6 +288,14 @@ def test_bwd_f32_ragged_head_dims(mfa, shape, causal):
     _f32_bwd_check(mfa, shape, shape[-1] ** -0.5, causal)
 
 
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("shape", [(1, 9, 1024, 64), (3, 5, 520, 128), (1, 1, 2048, 128), (1, 17, 300, 40)])
+def test_bwd_f32_many_blocks_and_heads(mfa, shape, causal):
+    """Long sequences (many 64-row blocks per head, many streamed blocks) and head counts that are no
+    multiple of 8 (the grid is padded to one: the padding workgroups leave in front of every barrier)."""
+    _f32_bwd_check(mfa, shape, shape[-1] ** -0.5, causal)
+
+
 @pytest.mark.parametrize("shape", [(1, 2, 256, 64), (1, 1, 192, 128)])
 def test_bwd_f32_unscaled_logits(mfa, shape):
     """scale = 1.0, the reference's semantics: logits of magnitude ~ 3 sqrt(d)."""
