@@ -6,7 +6,11 @@
 //   * a workgroup is four waves, one per SIMD, so that a wave may use all 512 registers of a lane:
 //     a 32-row operand held as MFMA fragments is d/4 registers (64 at d = 256) and a 32 x d float
 //     accumulator d/2 (128);
-//   * streamed tiles are 32 rows (16 KiB at d = 256), three LDS buffers per streamed tensor;
+//   * streamed tiles are 32 rows (16 KiB at d = 256), four LDS buffers per streamed tensor (the tile in
+//     use, the next one complete, two more in flight behind a counted wait);
+//   * S and dP are VGPR-form MFMAs and the gradient tile is pinned to accumulator registers (at this
+//     pressure the compiler otherwise parks every MFMA result in accumulator registers and moves S
+//     and dP out and back for the vector work);
 //   * dK and dV are two launches of one kernel (each holds ONE d-wide accumulator next to the K, V
 //     fragments; both passes form S, five tile products per pair of passes instead of four).
 // The reference has no backward (csrc/my_flash_attn/flash_attention.cu:23-69).
