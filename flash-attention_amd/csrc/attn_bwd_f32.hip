@@ -132,9 +132,12 @@ attn_bwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg, 
         if (orow < N) { own_l2 = lse[orow] * kLog2e; own_dl = dlt[orow]; }
     }
 
-    f32x4 acc1[NT], acc2[NT];                  // role dK/dV: dV, dK; role dQ: acc2 = dQ only
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc1[t] = acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Above 256 columns the owned fragments alone are half the register file: the output columns are
+    // then taken CS groups of NTC blocks at a time, each group in a walk of its own over the streamed
+    // side (S and dP are formed again in every walk).
+    constexpr int CS = DPAD > 256 ? (DQ ? 2 : 4) : 1;
+    constexpr int NTC = NT / CS;
+    f32x4 acc1[NTC], acc2[NTC];                // role dK/dV: dV, dK; role dQ: acc2 = dQ only
 
     // streamed blocks this workgroup needs
     const int nblk = (N + 15) >> 4;
@@ -185,9 +188,15 @@ attn_bwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg, 
         }
     };
 
+    float* o1 = out1 != nullptr ? out1 + hoff : nullptr;
+    float* o2 = out2 + hoff;
+#pragma nounroll
+    for (int cs = 0; cs < CS; ++cs) {
+#pragma unroll
+    for (int t = 0; t < NTC; ++t) acc1[t] = acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (nsb > 0) {
         fetch(block_at(0));
-        park(0);
+        park(0);                               // (a second walk: everybody left both buffers at the last barrier)
     }
     __syncthreads();
 
@@ -222,14 +231,15 @@ attn_bwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg, 
             p[r] = ok ? __builtin_amdgcn_exp2f(s[r] * sl2 - l2) : 0.f;
             ds[r] = p[r] * (dp[r] - dl);
         }
+        const int c0 = 16 * NTC * cs + j;      // this walk's first output column of the lane
 #pragma unroll
-        for (int cb = 0; cb < NT; ++cb)
+        for (int cb = 0; cb < NTC; ++cb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float b1 = y1[(4 * g + r) * LD + 16 * cb + j];
+                const float b1 = y1[(4 * g + r) * LD + 16 * cb + c0];
                 acc2[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[r], b1, acc2[cb], 0, 0, 0);
                 if constexpr (!DQ) {
-                    const float b2 = y2[(4 * g + r) * LD + 16 * cb + j];
+                    const float b2 = y2[(4 * g + r) * LD + 16 * cb + c0];
                     acc1[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[r], b2, acc1[cb], 0, 0, 0);
                 }
             }
@@ -238,19 +248,18 @@ attn_bwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg, 
         __syncthreads();
     }
 
-    // ---- store: accumulator cb, register r = owned row 4 g + r, column 16 cb + j
-    float* o1 = out1 != nullptr ? out1 + hoff : nullptr;
-    float* o2 = out2 + hoff;
+    // ---- store: accumulator cb, register r = owned row 4 g + r, column 16 (NTC cs + cb) + j
 #pragma unroll
-    for (int cb = 0; cb < NT; ++cb)
+    for (int cb = 0; cb < NTC; ++cb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = own0 + 4 * g + r, col = 16 * cb + j;
+            const int row = own0 + 4 * g + r, col = 16 * (NTC * cs + cb) + j;
             if (row < N && col < d) {
                 o2[(long long)row * d + col] = acc2[cb][r] * scale;
                 if constexpr (!DQ) o1[(long long)row * d + col] = acc1[cb][r];
             }
         }
+    }
 }
 
 template <int DPAD, bool CAUSAL, bool VEC>
@@ -288,12 +297,12 @@ int launch_f32_flags(const float* q, const float* k, const float* v, const float
 
 }  // namespace
 
-// Float32 tensors [heads, N, d], any d up to 256, any N; `delta`: float32 workspace of at least
+// Float32 tensors [heads, N, d], any d up to 512 (the float32 forward's range), any N; `delta`: float32 workspace of at least
 // heads * N elements (the caller's; the library allocates nothing).
 int attn_bwd_f32(const float* q, const float* k, const float* v, const float* o, const float* lse, const float* dout,
                  float* dq, float* dk, float* dv, float* delta, int64_t heads, int64_t N, int64_t d,
                  float scale, bool causal, hipStream_t s) {
-    if (d > 256) return fail(MYFA_E_UNSUPPORTED, "attention backward (float32): head dim %lld > 256", (long long)d);
+    if (d > 512) return fail(MYFA_E_UNSUPPORTED, "attention backward (float32): head dim %lld > 512", (long long)d);
     if (N * d >= (1LL << 31))
         return fail(MYFA_E_UNSUPPORTED, "attention backward (float32): N*d=%lld per head beyond the kernel's limit of 2^31", (long long)(N * d));
     // heads ride on the grid's y extent (rounded up to a multiple of 8): more go in successive launches
@@ -310,7 +319,8 @@ int attn_bwd_f32(const float* q, const float* k, const float* v, const float* o,
     if (d <= 32)  return launch_f32_flags<32>(q, k, v, o, lse, dout, dq, dk, dv, delta, heads, N, d, scale, causal, s);
     if (d <= 64)  return launch_f32_flags<64>(q, k, v, o, lse, dout, dq, dk, dv, delta, heads, N, d, scale, causal, s);
     if (d <= 128) return launch_f32_flags<128>(q, k, v, o, lse, dout, dq, dk, dv, delta, heads, N, d, scale, causal, s);
-    return launch_f32_flags<256>(q, k, v, o, lse, dout, dq, dk, dv, delta, heads, N, d, scale, causal, s);
+    if (d <= 256) return launch_f32_flags<256>(q, k, v, o, lse, dout, dq, dk, dv, delta, heads, N, d, scale, causal, s);
+    return launch_f32_flags<512>(q, k, v, o, lse, dout, dq, dk, dv, delta, heads, N, d, scale, causal, s);
 }
 
 }  // namespace myfa

@@ -749,7 +749,7 @@ int attn_bwd_f32(const float* q, const float* k, const float* v, const float* o,
                  float scale, bool causal, hipStream_t s);               // attn_bwd_f32.hip
 
 // dtype: MYFA_F16 or MYFA_BF16; d: 64, 128 (this file's kernels), 192 or 256 (attn_bwd_wide.hip);
-// or MYFA_F32 with any d up to 256 (attn_bwd_f32.hip).  heads = B*H.  `delta` is a caller-provided float32 workspace of 2 * heads * N elements (the
+// or MYFA_F32 with any d up to 512 (attn_bwd_f32.hip).  heads = B*H.  `delta` is a caller-provided float32 workspace of 2 * heads * N elements (the
 // library allocates nothing).
 int attn_bwd_mfma(const void* q, const void* k, const void* v, const void* o, const float* lse, const void* dout,
                   void* dq, void* dk, void* dv, float* delta, int64_t heads, int64_t N, int64_t d,
@@ -766,7 +766,7 @@ int attn_bwd_mfma(const void* q, const void* k, const void* v, const void* o, co
     if (dtype == MYFA_BF16 && d == 64)  return launch_bwd<__bf16, 64>(q, k, v, o, lse, dout, dq, dk, dv, delta, heads, N, scale, causal, s);
     if (dtype == MYFA_F16 && d == 128)  return launch_bwd<_Float16, 128>(q, k, v, o, lse, dout, dq, dk, dv, delta, heads, N, scale, causal, s);
     if (dtype == MYFA_F16 && d == 64)   return launch_bwd<_Float16, 64>(q, k, v, o, lse, dout, dq, dk, dv, delta, heads, N, scale, causal, s);
-    return fail(MYFA_E_UNSUPPORTED, "attention backward: needs float16 or bfloat16 with head dim 64, 128, 192 or 256, or float32 with head dim up to 256 (got dtype %d, d %lld)", dtype, (long long)d);
+    return fail(MYFA_E_UNSUPPORTED, "attention backward: needs float16 or bfloat16 with head dim 64, 128, 192 or 256, or float32 with head dim up to 512 (got dtype %d, d %lld)", dtype, (long long)d);
 }
 
 }  // namespace myfa

@@ -302,14 +302,19 @@ def attn_fwd_kernel_name(d, dtype, causal=False):
     return name.decode() if name else None
 
 
-BWD_MAX_HEAD_DIM = 256
-BWD_NATIVE_HEAD_DIMS = (64, 128, 192, 256)   # what the backward kernels are built for
+BWD_MAX_HEAD_DIM = 256                       # float16 / bfloat16
+BWD_MAX_HEAD_DIM_F32 = 512                   # float32: the float32 forward's whole range
+BWD_NATIVE_HEAD_DIMS = (64, 128, 192, 256)   # what the 16-bit backward kernels are built for
+
+
+def _bwd_max_head_dim(dtype):
+    return BWD_MAX_HEAD_DIM_F32 if dtype == torch.float32 else BWD_MAX_HEAD_DIM
 
 
 def flash_attn_bwd(dout, q, k, v, out, lse, scale=1.0, causal=False):
     """Gradients (dq, dk, dv) of flash_attn_fwd for float16 / bfloat16 / float32 (B, H, N, d)
-    tensors, d <= 256 (16-bit: 64, 128, 192 and 256 natively, the others through copies zero-padded
-    to the next of those; float32: any d natively).  `out` and `lse` are the forward's results
+    tensors: 16-bit with d <= 256 (64, 128, 192 and 256 natively, the others through copies zero-padded
+    to the next of those), float32 with any d <= 512 (natively).  `out` and `lse` are the forward's results
     (return_lse=True), `dout` the gradient of `out`.  The reference has no backward; this is the derivative of the forward
     it sketches (csrc/my_flash_attn/flash_attention.cu:23-69)."""
     for t, name in ((dout, "dout"), (q, "q"), (k, "k"), (v, "v"), (out, "out"), (lse, "lse")):
@@ -322,9 +327,8 @@ def flash_attn_bwd(dout, q, k, v, out, lse, scale=1.0, causal=False):
     if q.dtype not in _DTYPE_TAG:
         raise RuntimeError(f"flash_attn_bwd supports float16, bfloat16 and float32, got {q.dtype}")
     B, H, N, d = q.shape
-    if d > BWD_MAX_HEAD_DIM:
-        raise RuntimeError(f"flash_attn_bwd supports head dims up to {BWD_MAX_HEAD_DIM}, got {d} "
-                           "(float32 runs wider heads forward; a backward for them does not exist)")
+    if d > _bwd_max_head_dim(q.dtype):
+        raise RuntimeError(f"flash_attn_bwd supports head dims up to {_bwd_max_head_dim(q.dtype)} for {q.dtype}, got {d}")
     if lse.dtype != torch.float32 or tuple(lse.shape) != (B, H, N):
         raise RuntimeError("lse must be the float32 (B, H, N) tensor returned by flash_attn_fwd")
     if q.dtype != torch.float32 and d not in BWD_NATIVE_HEAD_DIMS and d > 0:
@@ -359,8 +363,8 @@ def flash_attn_bwd_into(dout, q, k, v, out, lse, dq, dk, dv, scale=1.0, causal=F
     if q.dtype not in _DTYPE_TAG:
         raise RuntimeError(f"flash_attn_bwd supports float16, bfloat16 and float32, got {q.dtype}")
     B, H, N, d = q.shape
-    if d > BWD_MAX_HEAD_DIM or (q.dtype != torch.float32 and d not in BWD_NATIVE_HEAD_DIMS):
-        raise RuntimeError(f"flash_attn_bwd_into supports head dims 64, 128, 192 and 256 (float32: any up to 256), got {d} "
+    if d > _bwd_max_head_dim(q.dtype) or (q.dtype != torch.float32 and d not in BWD_NATIVE_HEAD_DIMS):
+        raise RuntimeError(f"flash_attn_bwd_into supports head dims 64, 128, 192 and 256 (float32: any up to 512), got {d} "
                            "(flash_attn_bwd pads the others through copies, which this entry may not make)")
     if lse.dtype != torch.float32 or tuple(lse.shape) != (B, H, N):
         raise RuntimeError("lse must be the float32 (B, H, N) tensor returned by flash_attn_fwd")
@@ -375,9 +379,9 @@ def flash_attn_bwd_into(dout, q, k, v, out, lse, dq, dk, dv, scale=1.0, causal=F
 class _FlashAttnFunc(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, scale, causal):
-        if q.dtype not in _DTYPE_TAG or q.shape[-1] > BWD_MAX_HEAD_DIM:
-            raise RuntimeError(f"flash_attn_func is differentiable for float16 / bfloat16 / float32 and head dims up to "
-                               f"{BWD_MAX_HEAD_DIM}; got {q.dtype}, d = {q.shape[-1]} (use flash_attn_fwd for inference)")
+        if q.dtype not in _DTYPE_TAG or q.shape[-1] > _bwd_max_head_dim(q.dtype):
+            raise RuntimeError(f"flash_attn_func is differentiable for float16 / bfloat16 (head dims up to {BWD_MAX_HEAD_DIM}) and "
+                               f"float32 (up to {BWD_MAX_HEAD_DIM_F32}); got {q.dtype}, d = {q.shape[-1]} (use flash_attn_fwd for inference)")
         out, lse = flash_attn_fwd(q, k, v, scale=scale, return_lse=True, causal=causal)
         ctx.save_for_backward(q, k, v, out, lse)
         ctx.scale, ctx.causal = scale, causal
@@ -391,9 +395,9 @@ class _FlashAttnFunc(torch.autograd.Function):
 
 
 def flash_attn_func(q, k, v, scale=1.0, causal=False):
-    """flash_attn_fwd with autograd support: float16 / bfloat16 / float32, head dims up to 256
-    (16-bit: 64, 128, 192 and 256 natively, the others through zero-padded copies in the backward;
-    float32: any).  Wider heads (float32 forward up to 512) are refused here, before any work."""
+    """flash_attn_fwd with autograd support: float16 / bfloat16 with head dims up to 256 (64, 128, 192
+    and 256 natively, the others through zero-padded copies in the backward) and float32 with any head
+    dim up to 512, the forward's whole range.  Anything else is refused here, before any work."""
     return _FlashAttnFunc.apply(q, k, v, scale, causal)
 
 

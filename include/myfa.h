@@ -224,7 +224,9 @@ const char* myfa_attn_fwd_bhnd_kernel(int64_t d, int dtype, int flags);
 /*
  * Backward of myfa_attn_fwd_bhnd_ex for MYFA_F16 / MYFA_BF16, d in {64, 128, 192, 256}
  * (192 and 256: four-wave workgroups on 32-row tiles, dK and dV in separate launches), and for
- * MYFA_F32 with any d up to 256 (float32 matrix instructions, float32 throughout;
+ * MYFA_F32 with any d up to 512, the float32 forward's range (float32 matrix instructions, float32
+ * throughout; above 256 columns the kernels take the output columns in groups and walk the other
+ * side once per group;
  * N*d < 2^31 as in the float32 forward):
  * given the forward's inputs, its output `o`, its row log-sum-exp `lse` and the
  * gradient `dout` of the output, writes dq, dk, dv (same shape and dtype as q, k, v).

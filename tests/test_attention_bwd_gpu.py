@@ -296,6 +296,13 @@ def test_bwd_f32_many_blocks_and_heads(mfa, shape, causal):
     _f32_bwd_check(mfa, shape, shape[-1] ** -0.5, causal)
 
 
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("shape", [(1, 2, 100, 512), (1, 1, 200, 300), (2, 1, 65, 257), (1, 1, 33, 499)])
+def test_bwd_f32_head_dims_above_256(mfa, shape, causal):
+    """257..512: the output columns go in groups, each in a walk of its own over the other side."""
+    _f32_bwd_check(mfa, shape, shape[-1] ** -0.5, causal)
+
+
 @pytest.mark.parametrize("shape", [(1, 2, 256, 64), (1, 1, 192, 128)])
 def test_bwd_f32_unscaled_logits(mfa, shape):
     """scale = 1.0, the reference's semantics: logits of magnitude ~ 3 sqrt(d)."""

@@ -132,9 +132,9 @@ def test_wide_head_kernels_register_budgets():
 @pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="needs hipcc")
 def test_float32_backward_register_budgets():
     """The float32 backward keeps its owned fragments and its accumulators in registers for the whole
-    walk over the other side: no build may spill, the builds up to head dim 128 must leave room for
-    two workgroups per CU (256 registers), and the double-buffered blocks of the 256-column build
-    must fit the CU's LDS."""
+    walk over the other side: no build up to 256 columns may spill, the builds up to head dim 128 must
+    leave room for two workgroups per CU (256 registers), and the double-buffered blocks of the widest
+    build must fit the CU's LDS."""
     haz = _load("check_mfma_hazards", os.path.join(ROOT, "tools", "check_mfma_hazards.py"))
     build = _load("myfa_build", os.path.join(ROOT, "flash-attention_amd", "build.py"))
     src = "attn_bwd_f32.hip"
@@ -144,7 +144,9 @@ def test_float32_backward_register_budgets():
         m = re.search(r"attn_bwd_f32_kernelILi(\d+)E", name)
         assert m, name
         dpad = int(m.group(1))
-        assert r["vgpr_spill_count"] == 0 and r["sgpr_spill_count"] == 0, (name, r)
+        # (the 512-column build, for head dims 257..512, holds 256 registers of owned fragments and
+        # spills some tens of values: it exists for completeness of the range, not for speed)
+        assert r["sgpr_spill_count"] == 0 and r["vgpr_spill_count"] <= (0 if dpad <= 256 else 96), (name, r)
         assert r["vgpr_count"] <= (256 if dpad <= 128 else 512), (name, r)
         assert 4 * (4 * 16 * (dpad + 4) + 64) <= 160 * 1024
-    assert len(res) == 4 * 8, f"{len(res)} builds of the kernel found"
+    assert len(res) == 5 * 8, f"{len(res)} builds of the kernel found"

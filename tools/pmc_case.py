@@ -28,10 +28,13 @@ def main():
         fn = lambda: mfa.my_softmax(x, 1)  # noqa: E731
         note = f"algorithmic_bytes {2 * w * w * 4}"
     elif case.startswith("cols"):
-        w = int(case[len("cols"):])
+        bf = case.endswith("bf16")
+        w = int(case[len("cols"):-4] if bf else case[len("cols"):])
         x = torch.randn(w, w, device=dev)
+        if bf:
+            x = x.bfloat16()
         fn = lambda: mfa.softmax(x, dim=0)  # noqa: E731
-        note = f"algorithmic_bytes {2 * w * w * 4}"
+        note = f"algorithmic_bytes {2 * w * w * x.element_size()}"
     elif case in ("config3", "wide256", "causal", "scale1", "headline"):
         B, H, N, d, dt = {"config3": (8, 16, 1024, 64, torch.float16), "wide256": (4, 16, 4096, 256, torch.bfloat16),
                           "causal": (4, 32, 4096, 128, torch.bfloat16), "scale1": (4, 32, 4096, 128, torch.bfloat16),
