@@ -307,14 +307,17 @@ BWD_MAX_HEAD_DIM_F32 = 512                   # float32: the float32 forward's wh
 BWD_NATIVE_HEAD_DIMS = (64, 128, 192, 256)   # what the 16-bit backward kernels are built for
 
 
-def _bwd_max_head_dim(dtype):
-    return BWD_MAX_HEAD_DIM_F32 if dtype == torch.float32 else BWD_MAX_HEAD_DIM
+def _bwd_max_head_dim(dtype, native=False):
+    """Widest head dim of the backward: 16-bit tensors beyond 256 columns take the float32 kernels through
+    float32 copies (as their forward does), which an entry point that may not allocate cannot."""
+    return BWD_MAX_HEAD_DIM if native and dtype != torch.float32 else BWD_MAX_HEAD_DIM_F32
 
 
 def flash_attn_bwd(dout, q, k, v, out, lse, scale=1.0, causal=False):
     """Gradients (dq, dk, dv) of flash_attn_fwd for float16 / bfloat16 / float32 (B, H, N, d)
     tensors: 16-bit with d <= 256 (64, 128, 192 and 256 natively, the others through copies zero-padded
-    to the next of those), float32 with any d <= 512 (natively).  `out` and `lse` are the forward's results
+    to the next of those) and, like their forward, through float32 copies up to 512; float32 with any
+    d <= 512 (natively).  `out` and `lse` are the forward's results
     (return_lse=True), `dout` the gradient of `out`.  The reference has no backward; this is the derivative of the forward
     it sketches (csrc/my_flash_attn/flash_attention.cu:23-69)."""
     for t, name in ((dout, "dout"), (q, "q"), (k, "k"), (v, "v"), (out, "out"), (lse, "lse")):
@@ -331,6 +334,10 @@ def flash_attn_bwd(dout, q, k, v, out, lse, scale=1.0, causal=False):
         raise RuntimeError(f"flash_attn_bwd supports head dims up to {_bwd_max_head_dim(q.dtype)} for {q.dtype}, got {d}")
     if lse.dtype != torch.float32 or tuple(lse.shape) != (B, H, N):
         raise RuntimeError("lse must be the float32 (B, H, N) tensor returned by flash_attn_fwd")
+    if q.dtype != torch.float32 and d > BWD_MAX_HEAD_DIM:
+        # the forward of these shapes ran the float32 kernel on float32 copies; so does the backward
+        grads = flash_attn_bwd(dout.float(), q.float(), k.float(), v.float(), out.float(), lse, scale=scale, causal=causal)
+        return tuple(g.to(q.dtype) for g in grads)
     if q.dtype != torch.float32 and d not in BWD_NATIVE_HEAD_DIMS and d > 0:
         # zero columns up to the next head dim the kernels are built for change nothing
         pad = min(n for n in BWD_NATIVE_HEAD_DIMS if n > d) - d
@@ -363,7 +370,7 @@ def flash_attn_bwd_into(dout, q, k, v, out, lse, dq, dk, dv, scale=1.0, causal=F
     if q.dtype not in _DTYPE_TAG:
         raise RuntimeError(f"flash_attn_bwd supports float16, bfloat16 and float32, got {q.dtype}")
     B, H, N, d = q.shape
-    if d > _bwd_max_head_dim(q.dtype) or (q.dtype != torch.float32 and d not in BWD_NATIVE_HEAD_DIMS):
+    if d > _bwd_max_head_dim(q.dtype, native=True) or (q.dtype != torch.float32 and d not in BWD_NATIVE_HEAD_DIMS):
         raise RuntimeError(f"flash_attn_bwd_into supports head dims 64, 128, 192 and 256 (float32: any up to 512), got {d} "
                            "(flash_attn_bwd pads the others through copies, which this entry may not make)")
     if lse.dtype != torch.float32 or tuple(lse.shape) != (B, H, N):
@@ -380,8 +387,8 @@ class _FlashAttnFunc(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, scale, causal):
         if q.dtype not in _DTYPE_TAG or q.shape[-1] > _bwd_max_head_dim(q.dtype):
-            raise RuntimeError(f"flash_attn_func is differentiable for float16 / bfloat16 (head dims up to {BWD_MAX_HEAD_DIM}) and "
-                               f"float32 (up to {BWD_MAX_HEAD_DIM_F32}); got {q.dtype}, d = {q.shape[-1]} (use flash_attn_fwd for inference)")
+            raise RuntimeError(f"flash_attn_func is differentiable for float16 / bfloat16 / float32 and head dims up to "
+                               f"{BWD_MAX_HEAD_DIM_F32}; got {q.dtype}, d = {q.shape[-1]}")
         out, lse = flash_attn_fwd(q, k, v, scale=scale, return_lse=True, causal=causal)
         ctx.save_for_backward(q, k, v, out, lse)
         ctx.scale, ctx.causal = scale, causal
@@ -395,9 +402,10 @@ class _FlashAttnFunc(torch.autograd.Function):
 
 
 def flash_attn_func(q, k, v, scale=1.0, causal=False):
-    """flash_attn_fwd with autograd support: float16 / bfloat16 with head dims up to 256 (64, 128, 192
-    and 256 natively, the others through zero-padded copies in the backward) and float32 with any head
-    dim up to 512, the forward's whole range.  Anything else is refused here, before any work."""
+    """flash_attn_fwd with autograd support: float16 / bfloat16 / float32 with head dims up to 512,
+    everything flash_attn_fwd serves (16-bit: 64, 128, 192 and 256 natively, the others through zero-padded
+    copies, beyond 256 through float32 copies, in both directions; float32: any, natively).  Anything else
+    is refused here, before any work."""
     return _FlashAttnFunc.apply(q, k, v, scale, causal)
 
 

@@ -251,7 +251,7 @@ def test_bwd_causal_headline_shape(mfa):
             assert ours <= max(2.0 * torchs, 2e-2), (nm, ours, torchs)
 
 
-# ---- float32: float32 matrix instructions, any head dim up to 256, any N
+# ---- float32: float32 matrix instructions, any head dim up to 512, any N
 #
 # Tolerance: max |g - g_oracle| <= 2e-5 * max(|g_oracle|, 1) against the float64 oracle on the same
 # float32 inputs (the kernel recomputes exp(scale * S - lse) in float32: an error of a few 1e-6 in
@@ -343,6 +343,23 @@ def test_f32_more_heads_than_a_grid_holds(mfa):
         assert float((a.double() - r).abs().max()) <= F32_BWD_TOL * max(float(r.abs().max()), 1.0)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_bwd_16bit_head_dims_above_256(mfa, dtype):
+    """16-bit tensors beyond 256 columns: forward and backward both run the float32 kernels on float32
+    copies (host layer); flash_attn_func differentiates them."""
+    torch.manual_seed(11)
+    B, H, N, d = 1, 2, 90, 320
+    scale = d ** -0.5
+    q, k, v, do = (torch.randn(B, H, N, d) for _ in range(4))
+    qd, kd, vd = (x.cuda().to(dtype).requires_grad_(True) for x in (q, k, v))
+    out = mfa.flash_attn_func(qd, kd, vd, scale=scale, causal=True)
+    got = torch.autograd.grad(out, (qd, kd, vd), do.cuda().to(dtype))
+    ref = ref_cpu.attention_bwd_bhnd(*(_rounded(x, dtype) for x in (q, k, v, do)), scale=scale, causal=True)
+    for a, r in zip(got, ref):
+        assert a.dtype == dtype and a.shape == (B, H, N, d)
+        assert _rel(a.float().cpu().numpy(), r) <= REL
+
+
 def test_bwd_into_f32(mfa):
     """The entry point without a workspace argument serves float32 as well, bit for bit."""
     torch.manual_seed(6)
@@ -366,6 +383,6 @@ def test_bwd_errors(mfa):
         mfa.flash_attn_bwd(qb, qb, qb, qb, qb, lse[:, :, :32])
     with pytest.raises(RuntimeError, match="Wrong sizes"):
         mfa.flash_attn_bwd(qb, qb, qb[:, :, :32], qb, qb, lse)
-    wide = torch.randn(1, 1, 64, 264, device="cuda", dtype=torch.bfloat16)
-    with pytest.raises(RuntimeError, match="head dims up to 256"):
+    wide = torch.randn(1, 1, 64, 520, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="head dims up to 512"):
         mfa.flash_attn_bwd(wide, wide, wide, wide, wide, lse)
