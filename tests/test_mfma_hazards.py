@@ -69,7 +69,7 @@ def test_trans_use_checker():
 
 @pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="needs hipcc")
 @pytest.mark.parametrize("src,min_mfmas", [("attn_fwd_stream.hip", 0), ("attn_fwd_mfma16.hip", 0), ("attn_fwd_mfma256.hip", 8 * 48),
-                                           ("attn_bwd_mfma.hip", 8 * 32), ("attn_bwd_wide.hip", 0)])
+                                           ("attn_bwd_mfma.hip", 8 * 32), ("attn_bwd_wide.hip", 8 * 48)])
 def test_attention_kernels_keep_both_rules(src, min_mfmas):
     """Every attention source with inline asm beside transcendental instructions or with hand-written
     MFMAs: no early reader of an MFMA result, and no instruction reading a transcendental result one
