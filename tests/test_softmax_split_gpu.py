@@ -19,7 +19,7 @@ ATOL = 1e-5
 LOWP_REL = {torch.float16: 2.0 ** -11, torch.bfloat16: 2.0 ** -8}
 # (shape, dim): tall and narrow, ragged slices, several outer indices, rows of 4 / 8 / 16+ items
 SHAPES = [((5000, 16), 0), ((2, 3000, 36), 1), ((8192, 256), 0), ((4100, 1024), 0), ((100001, 24), 0),
-          ((3, 2050, 1024), 1), ((2100, 8192), 0), ((129, 8), 0)]
+          ((3, 2050, 1024), 1), ((2100, 1000), 0), ((129, 8), 0)]
 
 
 @pytest.fixture(scope="module")
@@ -154,6 +154,9 @@ def test_workspace_argument_checks(mfa):
     assert _lib.lib.myfa_softmax_nd_ws_bytes(64, 31, 100, _lib.MYFA_F32) == 0
     assert _lib.lib.myfa_softmax_nd_ws_bytes(1, 2000, 8192, _lib.MYFA_F32) == 0     # 1024 threads hold 2048 rows in registers
     assert _lib.lib.myfa_softmax_nd_ws_bytes(0, 5000, 64, _lib.MYFA_F32) == 0
+    # float32 rows wide enough for a workgroup per CU on 128-byte segments stream in one launch; 16-bit ones split
+    assert _lib.lib.myfa_softmax_nd_ws_bytes(1, 2100, 8192, _lib.MYFA_F32) == 0
+    assert _lib.lib.myfa_softmax_nd_ws_bytes(1, 2100, 8192, _lib.MYFA_BF16) > 0
     assert _lib.lib.myfa_softmax_nd_ws_bytes(1, 5000, 64, 77) == 0
 
 
