@@ -32,7 +32,10 @@ __device__ __forceinline__ void column_reduce(float (&v)[VW], float* red, int tx
 #pragma unroll
     for (int c = 0; c < VW; ++c) red[ty * W + c * TX + tx] = v[c];
     __syncthreads();
-    if constexpr (TY <= 16) {
+    // (few rows of partials: every thread adds them up itself; the unrolled reads of TY * VW values are
+    // all in flight at once, so with eight-element items this form stops at eight rows: at sixteen it
+    // made the 16-bit kernels 143 registers wide, three waves per SIMD)
+    if constexpr (TY * VW <= 64) {
 #pragma unroll
         for (int c = 0; c < VW; ++c) {
             float r = red[c * TX + tx];
@@ -223,7 +226,8 @@ softmax_cols_stream(const E* __restrict__ in, E* __restrict__ out, int64_t len, 
         // memory round trip each, on the critical path of the launch's last workgroups).
         const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)(part - tx * VW), 0, (unsigned)((size_t)nsplit * 2 * W * sizeof(float)), 0x00020000);
         constexpr int kSc1 = 16;
-#pragma unroll 4
+        constexpr int MERGE_UNROLL = VW == 8 ? 1 : 4;    // (2 VW loads an iteration: sixteen are enough in flight)
+#pragma unroll MERGE_UNROLL
         for (int sp = ty; sp < nsplit; sp += TY) {
             float pmv[VW], plv[VW];
 #pragma unroll
