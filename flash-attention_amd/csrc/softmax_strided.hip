@@ -130,8 +130,7 @@ template <typename E, int TX, int VW, int BLOCK, bool PRO = false, int PHASE = 0
 __global__ void __launch_bounds__(BLOCK)
 softmax_cols_stream(const E* __restrict__ in, E* __restrict__ out, int64_t len, int64_t inner, int64_t nchunk, Prologue pro,
                     int64_t groups, int nsplit, int64_t rows_per_split, unsigned* __restrict__ count, float* __restrict__ stats) {
-    // (eight-element items, 32 registers for four rows of them, take four rows at a time only in the 256-thread workgroups)
-    constexpr int TY = BLOCK / TX, U = (VW == 8 && BLOCK > 256) ? 2 : 4, W = TX * VW;
+    constexpr int TY = BLOCK / TX, U = 4, W = TX * VW;
     __shared__ float red[BLOCK * VW];
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     const int64_t id = PHASE == 2 ? (int64_t)gridDim.x - 1 - blockIdx.x : blockIdx.x;
@@ -337,10 +336,9 @@ SplitPlan split_plan(int64_t outer, int64_t len, int64_t inner, size_t esize) {
     if (reg_tx<VW>(outer, len, inner, esize) != 0) return p;
     if (reg_tx_big<VW>(outer, len, inner, esize) != 0) return p;
     const int64_t items = cdiv(inner, (int64_t)VW);
-    // float32 rows wide enough for one workgroup per CU on 128-byte segments stream at least as fast in
-    // one launch ([8192, 8192] over dim 0: 134 us against 140 split); 16-bit ones do not (their
-    // 1024- and 512-thread workgroups keep fewer bytes in flight: 154 us against 109)
-    if (VW == 4 && items >= 8 && outer * cdiv(items, (int64_t)8) >= 256) return p;
+    // rows wide enough for one workgroup per CU on 128-byte segments stream at least as fast in one
+    // launch (float32 [8192, 8192] over dim 0: 134 us against 140 split; float16 [4096, 32768]: 146 against 162)
+    if (VW > 1 && items >= 8 && outer * cdiv(items, (int64_t)8) >= 256) return p;
     int tx = 4;
     for (const int t : {16, 8}) if (items > t / 2) { tx = t; break; }
     const int64_t groups = outer * cdiv(items, (int64_t)tx);
@@ -403,7 +401,9 @@ int launch_cols(const E* in, E* out, int64_t outer, int64_t len, int64_t inner, 
 #undef MYFA_SPLIT
     }
     const bool big = len >= 2048;
-    constexpr int BIG = VW == 8 ? 512 : 1024;      // (eight-element items need the registers of a smaller workgroup)
+    // (16-bit items too: 1024 threads with four rows in flight each, 1.72 -> 2.51 TB/s at bf16 8192^2 over
+    // dim 0 against 512 threads with two, once the column statistics stopped costing 143 registers)
+    constexpr int BIG = 1024;
 #define MYFA_STREAM(TXV, LAST) \
     if (LAST || (items > TXV / 2 && blocks(TXV) >= 256)) { \
         const int64_t nchunk = cdiv(items, (int64_t)TXV); \
