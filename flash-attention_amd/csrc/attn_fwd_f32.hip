@@ -73,7 +73,10 @@ template <int NB> constexpr int max_waves() { return NB <= 4 ? 16 : NB <= 8 ? 8 
 // past d read the next key's first columns and only reach output columns that are not stored.
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <int NB, bool KT, bool VEC, bool CAUSAL = false, int BUF = 0>
-__global__ void __launch_bounds__(max_waves<NB>() * 64)
+// (256 columns, K as [N, d]: two four-wave workgroups per CU -- 235-243 registers, nothing spilled, where
+// the unconstrained allocation took 300-308 and left one wave per SIMD: B2 H16 N2048 d256 29 -> 50 TFLOP/s.
+// The transposed-K builds do not fit 256 registers: 46 spilled, 129 -> 175 us at 1024 x 200, so they keep one.)
+__global__ void __launch_bounds__(max_waves<NB>() * 64, (NB == 16 && !KT) ? 2 : 1)
 attn_fwd_f32_kernel(const float* __restrict__ Qg, const float* __restrict__ Kg,
                     const float* __restrict__ Vg, float* __restrict__ Og, float* __restrict__ LSEg,
                     int N, int d, int QG, int KS, long long head_stride, float scale,
