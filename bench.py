@@ -21,7 +21,7 @@ finds is the --gpus it was asked for.  Every rank runs the same per-GPU workload
                    against 8 TB/s HBM peak (rank 0, N=1 only)
   softmax_1024     my_softmax at 1024 x 1024 timed the way the reference's benchmark.py does, beside the
                    reference's published T4 numbers (the only timings it publishes)
-  softmax_dim      softmax along a non-last dimension (8 algorithmic B/element), and
+  softmax_dim      softmax along a non-last dimension (8 algorithmic B/element in float32, 4 in bfloat16), and
   matmul_f32       my_matmul at n^3 against the 157.3 TFLOP/s float32 MFMA peak beside the vendor GEMM
   cpu_config1      torch CPU timings of the CPU reference configuration (softmax 1024^2, naive attention
                    N=128 d=64), for reference beside the GPU numbers
@@ -269,16 +269,18 @@ def bench_softmax_dim(mfa):
     2048-row columns), streamed columns, and tall narrow tensors (rows of a column block split over
     workgroups)."""
     res = []
-    for shape, dim in (((256, 64, 64, 64), 1), ((64, 128, 16384), 1), ((4, 8, 2048, 2048), 2), ((8192, 8192), 0), ((16384, 4096), 0), ((100000, 512), 0)):
-        xs = [torch.randn(*shape, dtype=torch.float32, device="cuda") for _ in range(3)]
+    f32, bf16 = torch.float32, torch.bfloat16
+    for shape, dim, dt in (((256, 64, 64, 64), 1, f32), ((64, 128, 16384), 1, f32), ((4, 8, 2048, 2048), 2, f32), ((8192, 8192), 0, f32),
+                           ((16384, 4096), 0, f32), ((100000, 512), 0, f32), ((4, 8, 2048, 2048), 2, bf16), ((8192, 8192), 0, bf16)):
+        xs = [torch.randn(*shape, dtype=torch.float32, device="cuda").to(dt) for _ in range(3)]
         i = [0]
 
         def run():
             i[0] += 1
             return mfa.softmax(xs[i[0] % 3], dim=dim)
         ms = _median_ms(run, iters=20)
-        gbs = 2.0 * xs[0].numel() * 4 / (ms * 1e-3) / 1e9
-        res.append({"shape": list(shape), "dim": dim, "us": round(ms * 1e3, 2), "GB/s": round(gbs, 1),
+        gbs = 2.0 * xs[0].numel() * xs[0].element_size() / (ms * 1e-3) / 1e9
+        res.append({"shape": list(shape), "dim": dim, "dtype": "f32" if dt == f32 else "bf16", "us": round(ms * 1e3, 2), "GB/s": round(gbs, 1),
                     "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
         del xs
         torch.cuda.empty_cache()
